@@ -1,0 +1,145 @@
+/* pt355 -- C ABI of the MI355X-native render hot path.
+ *
+ * This library replaces ONE seam of limepixl/pathtracer: the OpenGL upload +
+ * compute dispatch of shaders/framebuffer.comp.  Every entry point below names
+ * the reference interface it stands in for (paths relative to the reference
+ * repository root).  Plain C types only; no exceptions cross this boundary; all
+ * functions return 0 on success and a PT_E* code otherwise (pt_last_error gives
+ * the text).  One pt_ctx per host thread; one HIP stream per context.
+ *
+ * Buffer layouts are the reference's, byte for byte:
+ *   sphere    32 B  src/scene/sphere.hpp:7-15      shaders/framebuffer.comp:54-58
+ *   triangle  64 B  src/scene/triangle.hpp:26-43   shaders/framebuffer.comp:46-52  (BVH leaf order)
+ *   material  48 B  src/scene/material.hpp:13-31   shaders/framebuffer.comp:60-65
+ *   bvh node  32 B  src/scene/bvh.h:7-14           shaders/framebuffer.comp:67-71
+ *   camera    48 B  src/scene/camera.hpp:26-39     shaders/framebuffer.comp:14-19
+ *   framedata 16 B  src/display/display.hpp:7-13   shaders/framebuffer.comp:21-24
+ */
+#ifndef PT355_H
+#define PT355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_EINVAL 1   /* bad argument / shape the kernels do not accept */
+#define PT_EHIP 2     /* a HIP call failed; pt_last_error has hipGetErrorString */
+#define PT_ESTATE 3   /* call order: e.g. render before upload_scene/set_camera */
+#define PT_ENOMEM 4
+
+typedef struct pt_ctx pt_ctx;
+
+/* pt_config.flags */
+#define PT_FLAG_SHADOW_ANYHIT      1u /* NEE visibility by any-hit traversal (fast mode). Default (0) is the
+                                         reference's closest-hit + point compare, framebuffer.comp:970-974. */
+#define PT_FLAG_TRACE_DEAD_PATHS   2u /* keep tracing paths whose throughput is exactly 0 (the reference does,
+                                         framebuffer.comp:899-1078); default retires them: same image, fewer rays */
+#define PT_FLAG_COUNT_TRAVERSAL    4u /* accumulate node-pair visits / triangle tests (slower; for roofline inputs) */
+
+/* pt_config.partition: how the image is shared between the ranks of one node */
+#define PT_PARTITION_TILES   0u /* 8x8 tiles dealt round-robin: tile t belongs to rank t % world */
+#define PT_PARTITION_FULL    1u /* every rank owns every pixel (single GPU, or sample-interleaved frames) */
+
+/* Replaces: Display::Display / InitRenderBuffer (src/display/display.cpp:34-199) as far as the compute
+ * path needs it -- the RGBA32F image (image unit 0), FrameData UBO (binding 4) -- and the constants of
+ * src/defines.hpp:15-21. width and height must be multiples of 8 (glDispatchCompute(W/8,H/8,1)). */
+typedef struct pt_config {
+	uint32_t width, height;
+	int32_t  device;       /* HIP device ordinal */
+	uint32_t flags;
+	uint32_t partition;    /* PT_PARTITION_* */
+	uint32_t rank, world;  /* this context's share; world = 0 or 1 means the whole image */
+	uint32_t reserved[9];
+} pt_config;
+
+/* Replaces: the six PushDataToSSBO calls, bindings 0..5 in call order (src/main.cpp:57-63,
+ * src/core/utils.h:6-19; shader side framebuffer.comp:75-103) and the two sampler units
+ * (env map: src/display/display.cpp:174-193; texture array: src/loader.cpp:50-58,242-265).
+ * Arrays are copied; the caller keeps ownership.  Empty arrays (count 0) may be NULL. */
+typedef struct pt_scene_desc {
+	const void     *spheres;        uint32_t n_spheres;
+	const void     *tris;           uint32_t n_tris;
+	const uint32_t *light_tris;     uint32_t n_light_tris;
+	const void     *materials;      uint32_t n_materials;
+	const void     *nodes;          uint32_t n_nodes;
+	const uint32_t *light_spheres;  uint32_t n_light_spheres;
+	const uint8_t  *env_rgb8;       uint32_t env_w, env_h;   /* NULL: texture without storage -> black */
+	const uint8_t  *tex_rgb8;       uint32_t tex_layers;     /* 512 x 512 x layers, RGB8 */
+} pt_scene_desc;
+
+/* Rays are counted when they are enqueued to a trace kernel. */
+typedef struct pt_counters {
+	uint64_t frames;
+	uint64_t paths;          /* pixel-samples started */
+	uint64_t rays_primary;
+	uint64_t rays_shadow;
+	uint64_t rays_bounce;
+	uint64_t node_steps;     /* only with PT_FLAG_COUNT_TRAVERSAL */
+	uint64_t tri_tests;      /* only with PT_FLAG_COUNT_TRAVERSAL */
+	uint64_t stack_spills;   /* traversal-stack pushes that left the LDS short stack */
+	double   ms_trace;       /* HIP-event time of all trace launches since the last reset */
+	double   ms_shade;       /* ... of raygen + shade launches */
+	uint64_t trace_launches;
+	uint64_t reserved[5];
+} pt_counters;
+
+int pt_create(const pt_config *cfg, pt_ctx **out);
+int pt_destroy(pt_ctx *ctx);
+const char *pt_last_error(const pt_ctx *ctx); /* ctx may be NULL: error of the last failed pt_create */
+
+int pt_upload_scene(pt_ctx *ctx, const pt_scene_desc *scene);
+
+/* Replaces: glNamedBufferSubData(cam.cam_ubo, ...) of src/main.cpp:90-94 (CameraGLSL = 12 floats). */
+int pt_set_camera(pt_ctx *ctx, const float cam[12]);
+
+/* Replaces: one iteration of src/main.cpp:97-101 -- FrameData upload, glDispatchCompute(W/8,H/8,1),
+ * glMemoryBarrier.  frame_data = {seed, frame#, bounces, 0}.  One sample per pixel, blended into the
+ * running mean with weight 1/(frame#+1) (framebuffer.comp:1124-1129).  Asynchronous on the context's
+ * stream; pt_sync or any read-back orders it. */
+int pt_render_frame(pt_ctx *ctx, const uint32_t frame_data[4]);
+
+/* n_frames consecutive pt_render_frame calls: frame numbers first_frame.., seeds[i] per frame. */
+int pt_render(pt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces);
+
+int pt_sync(pt_ctx *ctx);
+
+/* The reference never reads the image back (it blits it: src/main.cpp:108-114); a headless build must.
+ * rgba receives width*height*4 floats, row 0 = bottom row of the displayed image. */
+int pt_read_framebuffer(pt_ctx *ctx, float *rgba, size_t n_floats);
+int pt_clear_framebuffer(pt_ctx *ctx);
+/* Device address of the RGBA32F image, for callers that move it with RCCL (torch.distributed). */
+int pt_framebuffer_device(pt_ctx *ctx, void **dev_ptr);
+
+/* Test / bench boundary for the bit-exact closest-hit contract: intersect() of
+ * framebuffer.comp:423-456 for n rays (AoS xyz, host memory).  kind: 0 miss, 1 triangle, 2 sphere;
+ * prim: full 32-bit primitive index; t_h: fp16 bits of HitData.t; uv: optional, 2 floats per ray. */
+int pt_trace_closest(pt_ctx *ctx, const float *ro, const float *rd, uint32_t n,
+                     uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv);
+/* Same kernel on rays already resident in HBM, structure-of-arrays: ray6 = ro.x[n] ro.y[n] ro.z[n]
+ * rd.x[n] rd.y[n] rd.z[n]; hit4 = prim[n] (u32) tk[n] (t_h | kind<<16) u[n] v[n].  Asynchronous. */
+int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
+
+int pt_get_counters(pt_ctx *ctx, pt_counters *out);
+int pt_reset_counters(pt_ctx *ctx);
+
+/* Multi-GPU (no counterpart in the reference, which is single-GPU): the pixels a rank owns, in the
+ * order pt_pack_owned writes them.  Pure host arithmetic -- usable without a GPU. */
+uint32_t pt_partition_count(uint32_t width, uint32_t height, uint32_t partition, uint32_t rank, uint32_t world);
+int pt_partition_pixels(uint32_t width, uint32_t height, uint32_t partition, uint32_t rank, uint32_t world,
+                        uint32_t *pixels /* y*width+x, pt_partition_count entries */);
+/* framebuffer -> dst_dev: RGBA of this rank's pixels, packed in pt_partition_pixels order (device memory). */
+int pt_pack_owned(pt_ctx *ctx, void *dst_dev);
+/* src_dev (packed by rank `from_rank` of `world`) -> this context's framebuffer. */
+int pt_unpack_from(pt_ctx *ctx, const void *src_dev, uint32_t from_rank, uint32_t world);
+
+/* Numerics self-test hook: evaluates one primitive of the arithmetic contract on the device
+ * (op codes as in oracle/oracle.h) so tests can pin device min/max/div/sqrt/fp16/transcendentals. */
+int pt_debug_eval(pt_ctx *ctx, int op, const float *a, const float *b, uint32_t n, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

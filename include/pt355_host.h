@@ -1,0 +1,87 @@
+/* pt355 host side -- the CPU pieces of the path that the north star keeps on the host:
+ * SSBO packing, the Sweep-SAH BVH build, emissive-primitive lists, the per-frame host PCG seed,
+ * procedural stand-in scenes and the display transfer function.  Part of libpt355.so, no GPU needed.
+ * Each entry names the reference code whose OUTPUT BYTES it reproduces (tests pin them against the
+ * reference's own translation units compiled in the build container: oracle/_ref).
+ */
+#ifndef PT355_HOST_H
+#define PT355_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+#include "pt355.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MaterialType, src/scene/material.hpp:5-11 */
+#define PTH_MAT_LIGHT          (-1)
+#define PTH_MAT_LAMBERTIAN       0
+#define PTH_MAT_OREN_NAYAR       1
+#define PTH_MAT_SPECULAR_METAL   2
+
+/* glm::packHalf2x16 as the reference uses it (thirdparty/glm/glm/detail/type_half.inl:105-238:
+ * round-half-up on the magnitude, not RTNE) -- src/scene/triangle.cpp:53-62 */
+uint32_t pth_pack_half2x16(float x, float y);
+/* pixl::octahedral_normal_encoding, src/math/math.cpp:196-211 */
+void pth_oct_encode(const float n[3], float out[2]);
+/* TriangleGLSL::TriangleGLSL, src/scene/triangle.cpp:49-64.  v, n: 3x xyz; uv: 3x st. */
+void pth_pack_triangle(const float v[9], const float uv[6], const float n[9], uint32_t mat_index, void *out64);
+/* MaterialGLSL::MaterialGLSL, src/scene/material.cpp:7-22 (metal roughness clamped to >= 0.01) */
+void pth_pack_material(const float diffuse[3], const float specular[3], const float le[3], float roughness,
+                       int tex_index, int type, void *out48);
+/* SphereGLSL::SphereGLSL, src/scene/sphere.cpp:5-9 */
+void pth_pack_sphere(const float origin[3], float radius, uint32_t mat_index, void *out32);
+/* CameraGLSL::CameraGLSL, src/scene/camera.cpp:75-80 */
+void pth_pack_camera(const float origin[3], const float forward[3], const float right[3], float speed, float sens,
+                     float out12[12]);
+
+/* CalculateBVH, src/scene/bvh.cpp:31-75 over bvh::SweepSahBuilder (thirdparty/bvh/include/bvh/
+ * sweep_sah_builder.hpp:43-254, top_down_builder.hpp:47-72, radix_sort.hpp:21-95), single-threaded
+ * order.  nodes_out: room for 2n+1 nodes; sorted_out: n triangles.  Returns the node count (0 on error). */
+uint32_t pth_build_bvh(const void *tris, uint32_t n, void *nodes_out, void *sorted_out);
+
+/* FindEmissiveTris, src/scene/triangle.cpp:73-86 (ANY Le component >= 1e-4) */
+uint32_t pth_find_emissive_tris(const void *tris, uint32_t n_tris, const void *mats, uint32_t n_mats, uint32_t *out);
+/* FindEmissiveSpheres, src/scene/sphere.cpp:11-24 (ALL Le components > 1e-4) */
+uint32_t pth_find_emissive_spheres(const void *spheres, uint32_t n_spheres, const void *mats, uint32_t n_mats,
+                                   uint32_t *out);
+
+/* pcg32_random() on the default global stream, src/main.cpp:97 with
+ * thirdparty/pcg-c-basic-0.9/pcg_basic.c:35,60-72: outputs number first..first+n-1 since process start. */
+void pth_frame_seeds(uint32_t first, uint32_t n, uint32_t *out);
+
+/* ---- scene container: what src/main.cpp:18-63 assembles before the uploads -------------------- */
+typedef struct pth_scene pth_scene;
+pth_scene *pth_scene_create(void);
+void pth_scene_destroy(pth_scene *s);
+int pth_scene_add_material(pth_scene *s, const float diffuse[3], const float specular[3], const float le[3],
+                           float roughness, int tex_index, int type); /* returns the material index */
+int pth_scene_add_sphere(pth_scene *s, const float origin[3], float radius, uint32_t mat_index);
+/* count "fat" triangles (src/scene/triangle.hpp:8-24): v 9 floats, n 9 floats, uv 6 floats (uv may be NULL) */
+int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const float *uv, const uint32_t *mat,
+                            uint32_t count);
+/* Model::ConvertToSSBOFormat + CalculateBVH + FindEmissive* (src/main.cpp:31-55) */
+int pth_scene_finalize(pth_scene *s);
+/* pointers stay valid until the next mutation / destroy */
+int pth_scene_desc(const pth_scene *s, pt_scene_desc *out);
+uint64_t pth_scene_hash(const pth_scene *s); /* FNV-1a over the six arrays, binding order */
+
+/* Procedural stand-ins (no assets exist offline: the reference git-ignores .glb / .hdr files).
+ * Cornell box: 5 walls + ceiling light quad + two boxes = 36 triangles, placed like src/main.cpp:26-28.
+ * flags bit0: add the four gold GGX spheres of src/main.cpp:44-51. */
+int pth_scene_make_cornell(pth_scene *s, uint32_t flags);
+/* Cornell box + a displaced icosphere ("bunny stand-in"): subdiv 6 -> 81,920 triangles; `target_tris`
+ * > 0 trims to that count (69,451 for the Stanford bunny).  mesh_material: PTH_MAT_*; flags as above. */
+int pth_scene_make_bunny(pth_scene *s, uint32_t subdiv, uint32_t target_tris, uint32_t seed, int mesh_material,
+                         float mesh_roughness, uint32_t flags);
+/* n_tris random small triangles in the box (BVH / traversal stress; LCG s = s*1664525+1013904223) */
+int pth_scene_make_soup(pth_scene *s, uint32_t n_tris, uint32_t seed, float size);
+
+/* shaders/framebuffer.frag:8-26: NaN -> red, Inf -> green, else pow(rgb, 1/2.2); 8-bit RGB out, top row first */
+int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

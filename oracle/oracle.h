@@ -1,0 +1,78 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's render hot path
+ * (shaders/framebuffer.comp), used as the parity checker by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product library
+ * (libpt355.so) never includes, links or calls anything declared here.
+ *
+ * Parity status: the reference ships no golden vectors for this path and its
+ * GLSL cannot be executed in the build container, so the
+ * integrator half of this oracle is "parity unpinned" by the reference's own
+ * fixtures; it is pinned instead by (i) line-by-line citation of
+ * framebuffer.comp, (ii) the reference's own host TUs for every buffer it
+ * consumes (oracle/_ref), and (iii) closed-form / libm cross-checks in tests/.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The six SSBOs in binding order (src/main.cpp:57-63) plus the two samplers. */
+typedef struct oracle_scene {
+	const void *spheres;        uint32_t n_spheres;        /* binding 0, 32 B each  */
+	const void *tris;           uint32_t n_tris;           /* binding 1, 64 B each, BVH leaf order */
+	const uint32_t *light_tris; uint32_t n_light_tris;     /* binding 2 */
+	const void *materials;      uint32_t n_materials;      /* binding 3, 48 B each */
+	const void *nodes;          uint32_t n_nodes;          /* binding 4, 32 B each */
+	const uint32_t *light_spheres; uint32_t n_light_spheres; /* binding 5 */
+	const uint8_t *env_rgb8;    uint32_t env_w, env_h;     /* sampler unit 1 (NULL: no storage -> black) */
+	const uint8_t *tex_rgb8;    uint32_t tex_layers;       /* sampler unit 2, 512x512xN RGB8 (NULL: none) */
+} oracle_scene;
+
+typedef struct oracle_counters {
+	uint64_t paths;         /* pixel-samples started */
+	uint64_t rays_primary;  /* intersect() calls: framebuffer.comp:880  */
+	uint64_t rays_shadow;   /*                    framebuffer.comp:971  */
+	uint64_t rays_bounce;   /*                    framebuffer.comp:1023 */
+	uint64_t node_steps;    /* S: iterations of while(true) at framebuffer.comp:352 */
+	uint64_t tri_tests;     /* T: intersect_triangle calls, framebuffer.comp:371 */
+	uint64_t max_stack;     /* deepest traversal stack seen (reference has 16 slots) */
+	uint64_t reserved;
+} oracle_counters;
+
+#define ORACLE_FLAG_LIBM 1u /* transcendental functions from glibc instead of the spec'd ptm_* forms */
+
+/* intersect() of framebuffer.comp:423-456 for a batch of rays (AoS xyz).
+ * kind: 0 miss, 1 triangle, 2 sphere.  prim: full 32-bit index.  t_h: fp16 bits.
+ * uv (2 floats per ray, may be NULL): Moller-Trumbore u,v of the accepted hit.
+ * steps/tests (may be NULL): per-ray S and T. */
+int oracle_trace_closest(const oracle_scene *sc, const float *ro, const float *rd, uint32_t n,
+                         uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv,
+                         uint32_t *steps, uint32_t *tests);
+
+/* n_frames dispatches of main() (framebuffer.comp:1114-1130) into rgba (W*H*4
+ * floats, read-modify-write running mean).  Frame f uses FrameData =
+ * {seeds[f - first_frame], f, bounces, 0}. */
+int oracle_render(const oracle_scene *sc, const float cam[12], uint32_t width, uint32_t height,
+                  uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces,
+                  float *rgba, uint32_t flags, uint32_t n_threads, oracle_counters *counters);
+
+/* Unit-test hooks.  op codes are shared by convention with pt_debug_eval(). */
+enum {
+	ORACLE_OP_MIN = 0, ORACLE_OP_MAX = 1, ORACLE_OP_DIV = 2, ORACLE_OP_SQRT = 3,
+	ORACLE_OP_F2H2F = 4, /* float -> fp16 -> float */
+	ORACLE_OP_SIN = 5, ORACLE_OP_COS = 6, ORACLE_OP_TAN = 7, ORACLE_OP_ACOS = 8, ORACLE_OP_ATAN2 = 9,
+	ORACLE_OP_HADD = 10, ORACLE_OP_HMUL = 11, /* fp16 add / mul of the fp16-rounded inputs */
+	ORACLE_OP_RAND = 12 /* a = bit pattern of rng state; out = rand() float, b ignored */
+};
+int oracle_math(int op, const float *a, const float *b, uint32_t n, float *out);
+uint16_t oracle_f2h(float f);
+float oracle_h2f(uint16_t h);
+/* seed3 + n pcg() draws for pixel (x,y) and frame seed: framebuffer.comp:111-128 */
+void oracle_pcg_stream(uint32_t x, uint32_t y, uint32_t seed, uint32_t n, uint32_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,129 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product library.
+//
+// Thin extern "C" driver around the reference's OWN host translation units
+// (src/scene/{bvh,triangle,material,sphere}.cpp, src/math/math.cpp and
+// thirdparty/pcg-c-basic-0.9/pcg_basic.c), compiled from where they lie under
+// /root/reference by oracle/Makefile into oracle/_ref/libptref.so.
+//
+// It exists so that tests can pin, bit for bit, the build's own host pieces
+// (SSBO packing, Sweep-SAH BVH build, emissive lists, host PCG frame seeds)
+// against what the reference itself produces in this container.  Nothing of
+// the reference is copied: this file only *calls* it.  /root/reference does not
+// exist on the GPU box, so the vectors this library produces are committed as
+// fixtures under tests/golden/ (see tests/golden/make_golden.py).
+#include <cstdint>
+#include <cstring>
+
+#include "scene/bvh.h"        // BVHNodeGLSL, CalculateBVH   (src/scene/bvh.h:7-16)
+#include "scene/triangle.hpp" // TriangleGLSL, FindEmissiveTris (src/scene/triangle.hpp:26-45)
+#include "scene/material.hpp" // MaterialGLSL                 (src/scene/material.hpp:13-31)
+#include "scene/sphere.hpp"   // SphereGLSL, FindEmissiveSpheres (src/scene/sphere.hpp:7-18)
+#include "math/math.hpp"      // pixl::octahedral_normal_encoding (src/math/math.hpp)
+
+extern "C" {
+
+// sizes of the six layouts the boundary freezes
+void ref_sizes(uint32_t out[4])
+{
+	out[0] = (uint32_t) sizeof(TriangleGLSL);
+	out[1] = (uint32_t) sizeof(BVHNodeGLSL);
+	out[2] = (uint32_t) sizeof(MaterialGLSL);
+	out[3] = (uint32_t) sizeof(SphereGLSL);
+}
+
+// src/main.cpp:97 -- the per-frame seed is pcg32_random() on the global stream,
+// which starts from PCG32_INITIALIZER (pcg_basic.h).  The global is static inside
+// pcg_basic.c, so "process start" is restored by solving pcg32_srandom_r's two
+// steps (pcg_basic.c:42-49) for the (initstate, initseq) pair that lands on it.
+static uint64_t inv_mod_2_64(uint64_t a)
+{
+	uint64_t x = a; // Newton: doubles the number of correct low bits each step
+	for (int i = 0; i < 6; i++) x *= 2 - a * x;
+	return x;
+}
+void ref_pcg32_restart(void)
+{
+	const uint64_t S = 0x853c49e6748fea9bULL, I = 0xda3e39cb94b95bdbULL, M = 6364136223846793005ULL;
+	uint64_t initstate = (S - I) * inv_mod_2_64(M) - I;
+	pcg32_srandom(initstate, I >> 1);
+}
+uint32_t ref_pcg32_next(void) { return pcg32_random(); }
+
+// src/scene/triangle.cpp:49-64
+void ref_pack_triangle(const float v[9], const float uv[6], const float n[9], uint32_t mat_index, void *out64)
+{
+	TriangleGLSL t(glm::vec3(v[0], v[1], v[2]), glm::vec3(v[3], v[4], v[5]), glm::vec3(v[6], v[7], v[8]),
+	               glm::vec2(uv[0], uv[1]), glm::vec2(uv[2], uv[3]), glm::vec2(uv[4], uv[5]),
+	               glm::vec3(n[0], n[1], n[2]), glm::vec3(n[3], n[4], n[5]), glm::vec3(n[6], n[7], n[8]),
+	               mat_index);
+	memcpy(out64, &t, sizeof t);
+}
+
+// src/math/math.cpp:205-211
+void ref_oct_encode(const float n[3], float out[2])
+{
+	glm::vec2 e = pixl::octahedral_normal_encoding(glm::vec3(n[0], n[1], n[2]));
+	out[0] = e.x;
+	out[1] = e.y;
+}
+
+// src/scene/material.cpp:7-22
+void ref_pack_material(const float diffuse[3], const float specular[3], const float le[3], float roughness,
+                       int tex_index, int type, void *out48)
+{
+	MaterialGLSL m(glm::vec3(diffuse[0], diffuse[1], diffuse[2]), glm::vec3(specular[0], specular[1], specular[2]),
+	               glm::vec3(le[0], le[1], le[2]), roughness, tex_index, (MaterialType) type);
+	memcpy(out48, &m, sizeof m);
+}
+
+// src/scene/sphere.cpp:5-9
+void ref_pack_sphere(const float origin[3], float radius, uint32_t mat_index, void *out32)
+{
+	SphereGLSL s(glm::vec3(origin[0], origin[1], origin[2]), radius, mat_index);
+	memcpy(out32, &s, sizeof s);
+}
+
+// src/scene/bvh.cpp:31-75.  nodes_out must hold 2n+1 nodes, sorted_out n triangles.
+uint32_t ref_calculate_bvh(const void *tris_in, uint32_t n, void *nodes_out, void *sorted_out)
+{
+	Array<TriangleGLSL> in(n);
+	memcpy(in._data, tris_in, (size_t) n * sizeof(TriangleGLSL));
+	in.size = n;
+	Array<TriangleGLSL> sorted;
+	Array<BVHNodeGLSL> nodes = CalculateBVH(in, sorted);
+	memcpy(nodes_out, nodes._data, (size_t) nodes.size * sizeof(BVHNodeGLSL));
+	memcpy(sorted_out, sorted._data, (size_t) sorted.size * sizeof(TriangleGLSL));
+	return nodes.size;
+}
+
+// src/scene/triangle.cpp:73-86
+uint32_t ref_find_emissive_tris(const void *tris, uint32_t ntris, const void *mats, uint32_t nmats, uint32_t *out)
+{
+	Array<TriangleGLSL> t(ntris);
+	memcpy(t._data, tris, (size_t) ntris * sizeof(TriangleGLSL));
+	t.size = ntris;
+	Array<MaterialGLSL> m(nmats);
+	memcpy(m._data, mats, (size_t) nmats * sizeof(MaterialGLSL));
+	m.size = nmats;
+	Array<uint32> e = FindEmissiveTris(t, m);
+	for (uint32_t i = 0; i < e.size; i++) out[i] = e[i];
+	return e.size;
+}
+
+// src/scene/sphere.cpp:11-24
+uint32_t ref_find_emissive_spheres(const void *spheres, uint32_t nspheres, const void *mats, uint32_t nmats,
+                                   uint32_t *out)
+{
+	if (nspheres == 0) return 0;
+	Array<SphereGLSL> s(nspheres);
+	memcpy(s._data, spheres, (size_t) nspheres * sizeof(SphereGLSL));
+	s.size = nspheres;
+	Array<MaterialGLSL> m(nmats);
+	memcpy(m._data, mats, (size_t) nmats * sizeof(MaterialGLSL));
+	m.size = nmats;
+	Array<uint32> e = FindEmissiveSpheres(s, m);
+	for (uint32_t i = 0; i < e.size; i++) out[i] = e[i];
+	return e.size;
+}
+
+} // extern "C"

@@ -1,0 +1,393 @@
+// Scene container + procedural stand-in scenes + small host utilities (include/pt355_host.h).
+// Mirrors what src/main.cpp:18-63 assembles on the host before the six SSBO uploads.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/pt355_host.h"
+#include "layouts.h"
+
+struct pth_scene {
+	// "fat" input triangles (src/scene/triangle.hpp:8-24) until finalize packs them
+	std::vector<float> v, n, uv;
+	std::vector<uint32_t> mat;
+	// the six arrays, binding order 0..5
+	std::vector<PtSphere> spheres;
+	std::vector<PtTriangle> tris; // BVH leaf order after finalize
+	std::vector<uint32_t> light_tris;
+	std::vector<PtMaterial> materials;
+	std::vector<PtNode> nodes;
+	std::vector<uint32_t> light_spheres;
+	bool finalized = false;
+};
+
+namespace {
+
+struct Lcg { // s = s*1664525 + 1013904223
+	uint32_t s;
+	uint32_t next() { s = s * 1664525u + 1013904223u; return s; }
+	float unit() { return (float) (next() >> 8) * (1.0f / 16777216.0f); }
+};
+
+struct Vec { float x, y, z; };
+inline Vec vsub(Vec a, Vec b) { return Vec{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec vcross(Vec a, Vec b) { return Vec{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline Vec vnorm(Vec a)
+{
+	float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+	return l > 0 ? Vec{a.x / l, a.y / l, a.z / l} : Vec{0, 1, 0};
+}
+
+void push_tri(pth_scene *s, Vec a, Vec b, Vec c, Vec na, Vec nb, Vec nc, const float uvs[6], uint32_t m)
+{
+	const float vv[9] = {a.x, a.y, a.z, b.x, b.y, b.z, c.x, c.y, c.z};
+	const float nn[9] = {na.x, na.y, na.z, nb.x, nb.y, nb.z, nc.x, nc.y, nc.z};
+	pth_scene_add_triangles(s, vv, nn, uvs, &m, 1);
+}
+
+// quad a-b-c-d (counter-clockwise seen from the side its normal points to), flat normal
+void push_quad(pth_scene *s, Vec a, Vec b, Vec c, Vec d, uint32_t m)
+{
+	Vec nrm = vnorm(vcross(vsub(b, a), vsub(c, a)));
+	const float uv1[6] = {0, 0, 1, 0, 1, 1}, uv2[6] = {0, 0, 1, 1, 0, 1};
+	push_tri(s, a, b, c, nrm, nrm, nrm, uv1, m);
+	push_tri(s, a, c, d, nrm, nrm, nrm, uv2, m);
+}
+
+// axis-aligned box of half extents h, rotated by `angle` about +y, centred at c: 12 triangles
+void push_box(pth_scene *s, Vec c, Vec h, float angle, uint32_t m)
+{
+	const float ca = cosf(angle), sa = sinf(angle);
+	Vec p[8];
+	for (int i = 0; i < 8; i++) {
+		const float x = (i & 1) ? h.x : -h.x, y = (i & 2) ? h.y : -h.y, z = (i & 4) ? h.z : -h.z;
+		p[i] = Vec{c.x + ca * x + sa * z, c.y + y, c.z - sa * x + ca * z};
+	}
+	push_quad(s, p[4], p[5], p[7], p[6], m); // +z
+	push_quad(s, p[1], p[0], p[2], p[3], m); // -z
+	push_quad(s, p[5], p[1], p[3], p[7], m); // +x
+	push_quad(s, p[0], p[4], p[6], p[2], m); // -x
+	push_quad(s, p[2], p[6], p[7], p[3], m); // +y
+	push_quad(s, p[0], p[1], p[5], p[4], m); // -y
+}
+
+int add_mat(pth_scene *s, float dr, float dg, float db, float sr, float sg, float sb, float lr, float lg, float lb,
+            float rough, int type)
+{
+	const float d[3] = {dr, dg, db}, sp[3] = {sr, sg, sb}, le[3] = {lr, lg, lb};
+	return pth_scene_add_material(s, d, sp, le, rough, -1, type);
+}
+
+struct CornellMats { uint32_t white, red, green, light; };
+
+// the box occupies x,y in [-2,2], z in [-8,-4]; the camera sits at the origin looking down -z
+// (src/main.cpp:26-28 places the glb model around (0,0,-6); src/main.cpp:67 is the camera)
+CornellMats push_cornell_shell(pth_scene *s)
+{
+	CornellMats m;
+	m.white = (uint32_t) add_mat(s, 0.73f, 0.73f, 0.73f, 0, 0, 0, 0, 0, 0, 0.0f, PTH_MAT_LAMBERTIAN);
+	m.red = (uint32_t) add_mat(s, 0.65f, 0.05f, 0.05f, 0, 0, 0, 0, 0, 0, 0.0f, PTH_MAT_LAMBERTIAN);
+	m.green = (uint32_t) add_mat(s, 0.12f, 0.45f, 0.15f, 0, 0, 0, 0, 0, 0, 0.0f, PTH_MAT_LAMBERTIAN);
+	m.light = (uint32_t) add_mat(s, 0, 0, 0, 0, 0, 0, 17.0f, 12.0f, 4.0f, 0.0f, PTH_MAT_LIGHT);
+	const float x0 = -2, x1 = 2, y0 = -2, y1 = 2, z0 = -8, z1 = -4;
+	push_quad(s, Vec{x0, y0, z1}, Vec{x1, y0, z1}, Vec{x1, y0, z0}, Vec{x0, y0, z0}, m.white); // floor, +y
+	push_quad(s, Vec{x0, y1, z0}, Vec{x1, y1, z0}, Vec{x1, y1, z1}, Vec{x0, y1, z1}, m.white); // ceiling, -y
+	push_quad(s, Vec{x0, y0, z0}, Vec{x1, y0, z0}, Vec{x1, y1, z0}, Vec{x0, y1, z0}, m.white); // back, +z
+	push_quad(s, Vec{x0, y0, z1}, Vec{x0, y0, z0}, Vec{x0, y1, z0}, Vec{x0, y1, z1}, m.red);   // left, +x
+	push_quad(s, Vec{x1, y0, z0}, Vec{x1, y0, z1}, Vec{x1, y1, z1}, Vec{x1, y1, z0}, m.green); // right, -x
+	const float ly = 1.98f;
+	push_quad(s, Vec{-0.6f, ly, -6.6f}, Vec{0.6f, ly, -6.6f}, Vec{0.6f, ly, -5.4f}, Vec{-0.6f, ly, -5.4f}, m.light);
+	return m;
+}
+
+void push_gold_spheres(pth_scene *s) // src/main.cpp:44-51
+{
+	const float rough[4] = {0.0f, 0.1f, 0.15f, 0.2f};
+	const float cx[4] = {-1.0f, -0.4f, 0.2f, 0.8f};
+	for (int i = 0; i < 4; i++) {
+		int m = add_mat(s, 0, 0, 0, 0.944f, 0.776f, 0.373f, 0, 0, 0, rough[i], PTH_MAT_SPECULAR_METAL);
+		const float o[3] = {cx[i], 1.0f, -5.0f};
+		pth_scene_add_sphere(s, o, 0.3f, (uint32_t) m);
+	}
+}
+
+// radial displacement of the stand-in mesh: smooth lobes + seeded finer bumps
+struct Bumps {
+	float ph[6];
+	float radius(Vec d) const
+	{
+		float r = 1.0f;
+		r += 0.22f * sinf(2.0f * d.x + ph[0]) * sinf(3.0f * d.y + ph[1]);
+		r += 0.15f * sinf(4.0f * d.z + ph[2]) * cosf(2.0f * d.x + ph[3]);
+		r += 0.04f * sinf(11.0f * d.x + ph[4]) * sinf(13.0f * d.y + ph[5]) * sinf(9.0f * d.z + ph[0]);
+		r += 0.015f * sinf(37.0f * d.y + ph[2]) * sinf(41.0f * d.z + ph[1]);
+		return r;
+	}
+	Vec point(Vec d) const { float r = radius(d); return Vec{d.x * r, d.y * r, d.z * r}; }
+	Vec normal(Vec d) const
+	{
+		Vec t = fabsf(d.y) < 0.9f ? vnorm(vcross(Vec{0, 1, 0}, d)) : vnorm(vcross(Vec{1, 0, 0}, d));
+		Vec b = vcross(d, t);
+		const float e = 1e-3f;
+		Vec pa = point(vnorm(Vec{d.x + e * t.x, d.y + e * t.y, d.z + e * t.z}));
+		Vec pb = point(vnorm(Vec{d.x - e * t.x, d.y - e * t.y, d.z - e * t.z}));
+		Vec pc = point(vnorm(Vec{d.x + e * b.x, d.y + e * b.y, d.z + e * b.z}));
+		Vec pd = point(vnorm(Vec{d.x - e * b.x, d.y - e * b.y, d.z - e * b.z}));
+		Vec nn = vnorm(vcross(vsub(pa, pb), vsub(pc, pd)));
+		if (nn.x * d.x + nn.y * d.y + nn.z * d.z < 0) nn = Vec{-nn.x, -nn.y, -nn.z};
+		return nn;
+	}
+};
+
+uint64_t fnv1a(uint64_t h, const void *p, size_t n)
+{
+	const uint8_t *b = (const uint8_t *) p;
+	for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ULL; }
+	return h;
+}
+
+} // namespace
+
+extern "C" {
+
+pth_scene *pth_scene_create(void) { return new pth_scene(); }
+void pth_scene_destroy(pth_scene *s) { delete s; }
+
+int pth_scene_add_material(pth_scene *s, const float diffuse[3], const float specular[3], const float le[3],
+                           float roughness, int tex_index, int type)
+{
+	PtMaterial m;
+	pth_pack_material(diffuse, specular, le, roughness, tex_index, type, &m);
+	s->materials.push_back(m);
+	s->finalized = false;
+	return (int) s->materials.size() - 1;
+}
+
+int pth_scene_add_sphere(pth_scene *s, const float origin[3], float radius, uint32_t mat_index)
+{
+	PtSphere sp;
+	pth_pack_sphere(origin, radius, mat_index, &sp);
+	s->spheres.push_back(sp);
+	s->finalized = false;
+	return (int) s->spheres.size() - 1;
+}
+
+int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const float *uv, const uint32_t *mat,
+                            uint32_t count)
+{
+	if (!v || !n || !mat) return PT_EINVAL;
+	s->v.insert(s->v.end(), v, v + 9 * (size_t) count);
+	s->n.insert(s->n.end(), n, n + 9 * (size_t) count);
+	if (uv) s->uv.insert(s->uv.end(), uv, uv + 6 * (size_t) count);
+	else s->uv.insert(s->uv.end(), 6 * (size_t) count, 0.0f);
+	s->mat.insert(s->mat.end(), mat, mat + count);
+	s->finalized = false;
+	return PT_OK;
+}
+
+int pth_scene_finalize(pth_scene *s)
+{
+	const size_t n = s->mat.size();
+	if (n == 0) return PT_EINVAL;
+	for (size_t i = 0; i < n; i++)
+		if (s->mat[i] >= s->materials.size()) return PT_EINVAL;
+	for (const PtSphere &sp : s->spheres)
+		if (sp.mat >= s->materials.size()) return PT_EINVAL;
+	std::vector<PtTriangle> unsorted(n);
+	for (size_t i = 0; i < n; i++)
+		pth_pack_triangle(&s->v[9 * i], &s->uv[6 * i], &s->n[9 * i], s->mat[i], &unsorted[i]);
+	s->tris.resize(n);
+	s->nodes.resize(2 * n + 1);
+	uint32_t nn = pth_build_bvh(unsorted.data(), (uint32_t) n, s->nodes.data(), s->tris.data());
+	if (nn == 0) return PT_EINVAL;
+	s->nodes.resize(nn);
+	s->light_tris.resize(n);
+	s->light_tris.resize(pth_find_emissive_tris(s->tris.data(), (uint32_t) n, s->materials.data(),
+	                                            (uint32_t) s->materials.size(), s->light_tris.data()));
+	s->light_spheres.resize(s->spheres.size());
+	s->light_spheres.resize(pth_find_emissive_spheres(s->spheres.data(), (uint32_t) s->spheres.size(),
+	                                                  s->materials.data(), (uint32_t) s->materials.size(),
+	                                                  s->light_spheres.data()));
+	s->finalized = true;
+	return PT_OK;
+}
+
+int pth_scene_desc(const pth_scene *s, pt_scene_desc *out)
+{
+	if (!s->finalized) return PT_ESTATE;
+	memset(out, 0, sizeof *out);
+	out->spheres = s->spheres.empty() ? nullptr : s->spheres.data();
+	out->n_spheres = (uint32_t) s->spheres.size();
+	out->tris = s->tris.data();
+	out->n_tris = (uint32_t) s->tris.size();
+	out->light_tris = s->light_tris.empty() ? nullptr : s->light_tris.data();
+	out->n_light_tris = (uint32_t) s->light_tris.size();
+	out->materials = s->materials.data();
+	out->n_materials = (uint32_t) s->materials.size();
+	out->nodes = s->nodes.data();
+	out->n_nodes = (uint32_t) s->nodes.size();
+	out->light_spheres = s->light_spheres.empty() ? nullptr : s->light_spheres.data();
+	out->n_light_spheres = (uint32_t) s->light_spheres.size();
+	return PT_OK;
+}
+
+uint64_t pth_scene_hash(const pth_scene *s)
+{
+	uint64_t h = 14695981039346656037ULL;
+	h = fnv1a(h, s->spheres.data(), s->spheres.size() * sizeof(PtSphere));
+	h = fnv1a(h, s->tris.data(), s->tris.size() * sizeof(PtTriangle));
+	h = fnv1a(h, s->light_tris.data(), s->light_tris.size() * 4);
+	h = fnv1a(h, s->materials.data(), s->materials.size() * sizeof(PtMaterial));
+	h = fnv1a(h, s->nodes.data(), s->nodes.size() * sizeof(PtNode));
+	h = fnv1a(h, s->light_spheres.data(), s->light_spheres.size() * 4);
+	return h;
+}
+
+uint32_t pth_find_emissive_tris(const void *tris_in, uint32_t n_tris, const void *mats_in, uint32_t n_mats, uint32_t *out)
+{
+	const PtTriangle *tris = (const PtTriangle *) tris_in;
+	const PtMaterial *mats = (const PtMaterial *) mats_in;
+	const float eps = 0.0001f; // EPSILON, src/math/math.hpp
+	uint32_t k = 0;
+	for (uint32_t i = 0; i < n_tris; i++) {
+		if (tris[i].mat >= n_mats) continue;
+		const float *le = mats[tris[i].mat].le;
+		if (le[0] >= eps || le[1] >= eps || le[2] >= eps) out[k++] = i;
+	}
+	return k;
+}
+
+uint32_t pth_find_emissive_spheres(const void *spheres_in, uint32_t n_spheres, const void *mats_in, uint32_t n_mats,
+                                   uint32_t *out)
+{
+	const PtSphere *sp = (const PtSphere *) spheres_in;
+	const PtMaterial *mats = (const PtMaterial *) mats_in;
+	const float eps = 0.0001f;
+	uint32_t k = 0;
+	for (uint32_t i = 0; i < n_spheres; i++) {
+		if (sp[i].mat >= n_mats) continue;
+		const float *le = mats[sp[i].mat].le;
+		if (le[0] > eps && le[1] > eps && le[2] > eps) out[k++] = i;
+	}
+	return k;
+}
+
+void pth_frame_seeds(uint32_t first, uint32_t n, uint32_t *out)
+{
+	// PCG-XSH-RR 64/32 from the library's static initialiser state (pcg_basic.h PCG32_INITIALIZER)
+	uint64_t state = 0x853c49e6748fea9bULL;
+	const uint64_t inc = 0xda3e39cb94b95bdbULL;
+	for (uint64_t i = 0; i < (uint64_t) first + n; i++) {
+		const uint64_t old = state;
+		state = old * 6364136223846793005ULL + inc;
+		const uint32_t xs = (uint32_t) (((old >> 18) ^ old) >> 27);
+		const uint32_t rot = (uint32_t) (old >> 59);
+		const uint32_t r = (xs >> rot) | (xs << ((32 - rot) & 31));
+		if (i >= first) out[i - first] = r;
+	}
+}
+
+int pth_scene_make_cornell(pth_scene *s, uint32_t flags)
+{
+	CornellMats m = push_cornell_shell(s);
+	push_box(s, Vec{0.65f, -1.4f, -5.4f}, Vec{0.6f, 0.6f, 0.6f}, -0.3f, m.white);  // short box
+	push_box(s, Vec{-0.7f, -0.8f, -6.6f}, Vec{0.6f, 1.2f, 0.6f}, 0.35f, m.white);  // tall box
+	if (flags & 1u) push_gold_spheres(s);
+	return pth_scene_finalize(s);
+}
+
+int pth_scene_make_bunny(pth_scene *s, uint32_t freq, uint32_t target_tris, uint32_t seed, int mesh_material,
+                         float mesh_roughness, uint32_t flags)
+{
+	if (freq == 0 || freq > 1024) return PT_EINVAL;
+	push_cornell_shell(s);
+	int mm;
+	if (mesh_material == PTH_MAT_SPECULAR_METAL)
+		mm = add_mat(s, 0, 0, 0, 0.944f, 0.776f, 0.373f, 0, 0, 0, mesh_roughness, PTH_MAT_SPECULAR_METAL);
+	else
+		mm = add_mat(s, 0.62f, 0.55f, 0.48f, 0, 0, 0, 0, 0, 0, mesh_roughness, mesh_material);
+
+	Lcg rng{seed * 2654435761u + 12345u};
+	Bumps bumps;
+	for (float &p : bumps.ph) p = 6.2831853f * rng.unit();
+
+	// class-I geodesic sphere: every icosahedron face cut into freq^2 triangles
+	const float t = 1.618033988749895f;
+	const Vec iv[12] = {{-1, t, 0}, {1, t, 0}, {-1, -t, 0}, {1, -t, 0}, {0, -1, t}, {0, 1, t},
+	                    {0, -1, -t}, {0, 1, -t}, {t, 0, -1}, {t, 0, 1}, {-t, 0, -1}, {-t, 0, 1}};
+	const int fi[20][3] = {{0, 11, 5}, {0, 5, 1}, {0, 1, 7}, {0, 7, 10}, {0, 10, 11}, {1, 5, 9}, {5, 11, 4},
+	                       {11, 10, 2}, {10, 7, 6}, {7, 1, 8}, {3, 9, 4}, {3, 4, 2}, {3, 2, 6}, {3, 6, 8},
+	                       {3, 8, 9}, {4, 9, 5}, {2, 4, 11}, {6, 2, 10}, {8, 6, 7}, {9, 8, 1}};
+	const Vec centre{0.0f, -0.85f, -6.0f};
+	const float scale = 0.95f;
+	uint32_t emitted = 0;
+	const uint32_t limit = target_tris ? target_tris : 0xffffffffu;
+	auto corner = [&](const Vec &a, const Vec &b, const Vec &c, uint32_t i, uint32_t j) {
+		const float fa = (float) (freq - i - j) / (float) freq, fb = (float) i / (float) freq, fc = (float) j / (float) freq;
+		return vnorm(Vec{a.x * fa + b.x * fb + c.x * fc, a.y * fa + b.y * fb + c.y * fc, a.z * fa + b.z * fb + c.z * fc});
+	};
+	auto emit = [&](Vec d0, Vec d1, Vec d2) {
+		if (emitted >= limit) return;
+		Vec d[3] = {d0, d1, d2}, p[3], nn[3];
+		float uvs[6];
+		for (int k = 0; k < 3; k++) {
+			Vec q = bumps.point(d[k]);
+			p[k] = Vec{centre.x + scale * q.x, centre.y + scale * q.y, centre.z + scale * q.z};
+			nn[k] = bumps.normal(d[k]);
+			uvs[2 * k] = atan2f(d[k].x, d[k].z) * (0.5f / 3.14159265f) + 0.5f;
+			uvs[2 * k + 1] = acosf(d[k].y > 1 ? 1 : (d[k].y < -1 ? -1 : d[k].y)) * (1.0f / 3.14159265f);
+		}
+		push_tri(s, p[0], p[1], p[2], nn[0], nn[1], nn[2], uvs, (uint32_t) mm);
+		emitted++;
+	};
+	for (int f = 0; f < 20; f++) {
+		const Vec a = vnorm(iv[fi[f][0]]), b = vnorm(iv[fi[f][1]]), c = vnorm(iv[fi[f][2]]);
+		for (uint32_t i = 0; i < freq; i++)
+			for (uint32_t j = 0; j + i < freq; j++) {
+				emit(corner(a, b, c, i, j), corner(a, b, c, i + 1, j), corner(a, b, c, i, j + 1));
+				if (i + j + 1 < freq)
+					emit(corner(a, b, c, i + 1, j), corner(a, b, c, i + 1, j + 1), corner(a, b, c, i, j + 1));
+			}
+	}
+	if (flags & 1u) push_gold_spheres(s);
+	return pth_scene_finalize(s);
+}
+
+int pth_scene_make_soup(pth_scene *s, uint32_t n_tris, uint32_t seed, float size)
+{
+	CornellMats m = push_cornell_shell(s);
+	int grey = add_mat(s, 0.5f, 0.5f, 0.5f, 0, 0, 0, 0, 0, 0, 0.3f, PTH_MAT_OREN_NAYAR);
+	Lcg rng{seed};
+	for (uint32_t i = 0; i < n_tris; i++) {
+		Vec c{-1.8f + 3.6f * rng.unit(), -1.8f + 3.6f * rng.unit(), -7.8f + 3.6f * rng.unit()};
+		Vec p[3];
+		for (int k = 0; k < 3; k++)
+			p[k] = Vec{c.x + size * (rng.unit() - 0.5f), c.y + size * (rng.unit() - 0.5f), c.z + size * (rng.unit() - 0.5f)};
+		Vec nrm = vnorm(vcross(vsub(p[1], p[0]), vsub(p[2], p[0])));
+		const float uvs[6] = {0, 0, 1, 0, 0, 1};
+		push_tri(s, p[0], p[1], p[2], nrm, nrm, nrm, uvs, (i % 7 == 0) ? m.red : (uint32_t) grey);
+	}
+	return pth_scene_finalize(s);
+}
+
+int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8)
+{
+	if (!rgba || !rgb8) return PT_EINVAL;
+	for (uint32_t y = 0; y < height; y++)
+		for (uint32_t x = 0; x < width; x++) {
+			const float *p = rgba + ((size_t) (height - 1 - y) * width + x) * 4; // row 0 is the bottom row
+			uint8_t *o = rgb8 + ((size_t) y * width + x) * 3;
+			const bool nan = p[0] != p[0] || p[1] != p[1] || p[2] != p[2] || p[3] != p[3];
+			const bool inf = std::isinf(p[0]) || std::isinf(p[1]) || std::isinf(p[2]) || std::isinf(p[3]);
+			if (nan) { o[0] = 255; o[1] = 0; o[2] = 0; continue; }
+			if (inf) { o[0] = 0; o[1] = 255; o[2] = 0; continue; }
+			for (int c = 0; c < 3; c++) {
+				float g = powf(p[c], 1.0f / 2.2f);
+				g = g < 0 ? 0 : (g > 1 ? 1 : g);
+				o[c] = (uint8_t) (g * 255.0f + 0.5f);
+			}
+		}
+	return PT_OK;
+}
+
+} // extern "C"
