@@ -139,6 +139,10 @@ int pt_unpack_from(pt_ctx *ctx, const void *src_dev, uint32_t from_rank, uint32_
  * (op codes as in oracle/oracle.h) so tests can pin device min/max/div/sqrt/fp16/transcendentals. */
 int pt_debug_eval(pt_ctx *ctx, int op, const float *a, const float *b, uint32_t n, float *out);
 
+/* Debug read-back of one column group of a path queue (queue 0/1; field: 0 pix, 1 rng, 2 meta, 3 thr, 4 col,
+ * 5 ray, 6 shadow ray, 7 nee, 8 bsdf, 9 hit, 10 shadow hit).  n_words = columns * stride.  No reference counterpart. */
+int pt_debug_read_queue(pt_ctx *ctx, uint32_t queue, uint32_t field, void *out, size_t n_words, uint32_t *stride, uint32_t *count);
+
 #ifdef __cplusplus
 }
 #endif

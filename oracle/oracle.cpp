@@ -20,6 +20,8 @@
 
 #include <atomic>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -445,6 +447,7 @@ struct Ctx {
 	const Scene &sc;
 	Fn fn;
 	Counters cn;
+	bool dbg = false;
 };
 
 // fc:141-152, returned transposed (fc:907): rows t, n, bt
@@ -695,6 +698,8 @@ v3 estimator_path_tracing_mis(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_
 	Mat mat_y = sc.mats[data.mat];
 
 	color = color + le_of(mat_y);
+	if (cx.dbg) printf("[cpu] stage 0 col %a %a %a | ro %a %a %a rd %a %a %a | hit prim %u t %a u %a v %a | n %a %a %a mat %u y %a %a %a\n", color.x, color.y, color.z,
+	                   ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, data.obj32, h2f(data.t), data.u, data.v, h2f(data.n[0]), h2f(data.n[1]), h2f(data.n[2]), data.mat, y.x, y.y, y.z);
 
 	uint32_t num_light_sources = sc.n_light_tris + sc.n_light_spheres;
 	uint32_t num_bounces = frame_bounces + 1;
@@ -734,11 +739,13 @@ v3 estimator_path_tracing_mis(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_
 				float r1 = rnd(rng_state), r2 = rnd(rng_state);
 				y_nee = map_to_unit_sphere(cx.fn, r1, r2) * radius + V(ls.d[0], ls.d[1], ls.d[2]);
 			}
+			if (cx.dbg) printf("[cpu]   nee b %u y_nee %08x %08x %08x area %a rng %08x\n", b, fbits(y_nee.x), fbits(y_nee.y), fbits(y_nee.z), light_area, rng_state);
 			v3 dist_vec = y_nee - x;
 			v3 shadow_rd = normalize(dist_vec);
 			v3 shadow_ro = x;
 			float squared_dist = dot(dist_vec, dist_vec);
 			float cos_theta_x = fmax_(0.0f, dot(hn(normal_x), shadow_rd));
+			if (cx.dbg) printf("[cpu]   x %08x %08x %08x srd %08x %08x %08x d2 %08x cosx %08x\n", fbits(x.x), fbits(x.y), fbits(x.z), fbits(shadow_rd.x), fbits(shadow_rd.y), fbits(shadow_rd.z), fbits(squared_dist), fbits(cos_theta_x));
 
 			Hit shadow_data;
 			cx.cn.shadow++;
@@ -805,6 +812,9 @@ v3 estimator_path_tracing_mis(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_
 		if (!can_use_NEE) {
 			if (mat_x.d2[3] == 2.0f) color = color + throughput_term * le_of(mat_y);
 		}
+		if (cx.dbg) printf("[cpu] stage %u col %a %a %a thr %a %a %a | ro %a %a %a rd %a %a %a | hit prim %u t %a u %a v %a | n %a %a %a mat %u y %a %a %a | brdf %a %a %a cos %a pdf %a\n", b, color.x, color.y, color.z,
+		                   throughput_term.x, throughput_term.y, throughput_term.z, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, data.obj32, h2f(data.t), data.u, data.v,
+		                   h2f(data.n[0]), h2f(data.n[1]), h2f(data.n[2]), data.mat, y.x, y.y, y.z, BRDF.x, BRDF.y, BRDF.z, cos_theta_x, pdf_BSDF_sa);
 	}
 	return color;
 }
@@ -862,6 +872,8 @@ int oracle_render(const oracle_scene *s, const float cam[12], uint32_t width, ui
 	if (n_threads == 0) n_threads = std::thread::hardware_concurrency();
 	if (n_threads == 0) n_threads = 1;
 	std::vector<Counters> per(n_threads);
+	const char *dbg_env = getenv("ORACLE_DEBUG_PIXEL");
+	const int dbg_px = dbg_env ? atoi(dbg_env) : -1;
 	for (uint32_t f = 0; f < n_frames; f++) {
 		uint32_t frame = first_frame + f, seed = seeds[f];
 		// 8x8 pixel blocks handed out dynamically (one GLSL work group each, fc:8)
@@ -877,6 +889,7 @@ int oracle_render(const oracle_scene *s, const float cam[12], uint32_t width, ui
 					for (uint32_t px = x0; px < x0 + 8 && px < width; px++) {
 						uint32_t rng_state = seed3(px, py, seed); // fc:1120
 						cx.cn.paths++;
+						cx.dbg = dbg_px == (int) (py * width + px);
 						v3 color = render_function(cx, cam, (float) width, (float) height, (int) px, (int) py, rng_state, bounces);
 						float *p = rgba + ((size_t) py * width + px) * 4; // fc:1126-1129
 						float fa = (float) frame / (float) (frame + 1), fb = 1.0f / (float) (frame + 1);
@@ -928,6 +941,30 @@ int oracle_math(int op, const float *a, const float *b, uint32_t n, float *out)
 		case ORACLE_OP_HADD: r = q16(q16(x) + q16(y)); break;
 		case ORACLE_OP_HMUL: r = q16(q16(x) * q16(y)); break;
 		case ORACLE_OP_RAND: { uint32_t st = fbits(x); r = rnd(st); break; }
+		case ORACLE_OP_OREN_NAYAR: case ORACLE_OP_GGX_NEE: case ORACLE_OP_GGX_IS: {
+			// composite BRDF probes: wo, wi cosine-sampled from the PCG stream seeded with the bits of a[i]
+			uint32_t st = fbits(x);
+			v3 up = V(0.0f, 1.0f, 0.0f);
+			float r1 = rnd(st), r2 = rnd(st);
+			v3 wo = normalize(map_to_unit_sphere(fn, r1, r2) + up);
+			Mat m; memset(&m, 0, sizeof m);
+			m.d1[3] = y; m.d2[0] = 0.944f; m.d2[1] = 0.776f; m.d2[2] = 0.373f; m.d2[3] = 2.0f; m.d3[3] = -1.0f;
+			if (op == ORACLE_OP_OREN_NAYAR) {
+				r1 = rnd(st); r2 = rnd(st);
+				v3 wi = normalize(map_to_unit_sphere(fn, r1, r2) + up);
+				r = oren_nayar_brdf(fn, V(1.0f, 0.5f, 0.25f), y, wi, wo).y;
+			} else if (op == ORACLE_OP_GGX_NEE) {
+				r1 = rnd(st); r2 = rnd(st);
+				v3 wi = normalize(map_to_unit_sphere(fn, r1, r2) + up);
+				r = GGX_Smith_BRDF_non_IS(wo, wi, V(m.d2[0], m.d2[1], m.d2[2]), y).x;
+			} else {
+				v3 wm; float c, pdf;
+				v3 wi = pick_wi(fn, wo, m, false, &wm, &c, &pdf, st);
+				v3 b3 = GGX_Smith_BRDF(wo, wm, wi, V(m.d2[0], m.d2[1], m.d2[2]), y);
+				r = b3.x + wi.y;
+			}
+			break;
+		}
 		default: return -1;
 		}
 		out[i] = r;

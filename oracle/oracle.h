@@ -64,7 +64,9 @@ enum {
 	ORACLE_OP_F2H2F = 4, /* float -> fp16 -> float */
 	ORACLE_OP_SIN = 5, ORACLE_OP_COS = 6, ORACLE_OP_TAN = 7, ORACLE_OP_ACOS = 8, ORACLE_OP_ATAN2 = 9,
 	ORACLE_OP_HADD = 10, ORACLE_OP_HMUL = 11, /* fp16 add / mul of the fp16-rounded inputs */
-	ORACLE_OP_RAND = 12 /* a = bit pattern of rng state; out = rand() float, b ignored */
+	ORACLE_OP_RAND = 12, /* a = bit pattern of rng state; out = rand() float, b ignored */
+	/* composite BRDF probes: directions drawn from the PCG stream seeded with the bits of a, b = roughness */
+	ORACLE_OP_OREN_NAYAR = 13, ORACLE_OP_GGX_NEE = 14, ORACLE_OP_GGX_IS = 15
 };
 int oracle_math(int op, const float *a, const float *b, uint32_t n, float *out);
 uint16_t oracle_f2h(float f);

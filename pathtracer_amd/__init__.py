@@ -1,0 +1,358 @@
+"""pathtracer_amd -- MI355X-native render hot path of limepixl/pathtracer behind a C ABI.
+
+This package is a thin ctypes view of ``libpt355.so`` (include/pt355.h, include/pt355_host.h).
+There is no Python or CPU implementation of the path behind it: if the library is missing, or no
+HIP device is present when a context is created, the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt355.so")
+
+PT_FLAG_SHADOW_ANYHIT = 1
+PT_FLAG_TRACE_DEAD_PATHS = 2
+PT_FLAG_COUNT_TRAVERSAL = 4
+PT_PARTITION_TILES = 0
+PT_PARTITION_FULL = 1
+MAT_LIGHT, MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_SPECULAR_METAL = -1, 0, 1, 2
+
+
+class PtError(RuntimeError):
+    pass
+
+
+class pt_config(ctypes.Structure):
+    _fields_ = [("width", c_uint32), ("height", c_uint32), ("device", c_int32), ("flags", c_uint32),
+                ("partition", c_uint32), ("rank", c_uint32), ("world", c_uint32), ("reserved", c_uint32 * 9)]
+
+
+class pt_scene_desc(ctypes.Structure):
+    _fields_ = [("spheres", c_void_p), ("n_spheres", c_uint32),
+                ("tris", c_void_p), ("n_tris", c_uint32),
+                ("light_tris", c_void_p), ("n_light_tris", c_uint32),
+                ("materials", c_void_p), ("n_materials", c_uint32),
+                ("nodes", c_void_p), ("n_nodes", c_uint32),
+                ("light_spheres", c_void_p), ("n_light_spheres", c_uint32),
+                ("env_rgb8", c_void_p), ("env_w", c_uint32), ("env_h", c_uint32),
+                ("tex_rgb8", c_void_p), ("tex_layers", c_uint32)]
+
+
+class pt_counters(ctypes.Structure):
+    _fields_ = [("frames", c_uint64), ("paths", c_uint64), ("rays_primary", c_uint64), ("rays_shadow", c_uint64),
+                ("rays_bounce", c_uint64), ("node_steps", c_uint64), ("tri_tests", c_uint64), ("stack_spills", c_uint64),
+                ("ms_trace", c_double), ("ms_shade", c_double), ("trace_launches", c_uint64), ("reserved", c_uint64 * 5)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+# every symbol include/pt355.h and include/pt355_host.h declare (tests check that all of them resolve)
+EXPORTS = {
+    "pt_create": (c_int, [POINTER(pt_config), POINTER(c_void_p)]),
+    "pt_destroy": (c_int, [c_void_p]),
+    "pt_last_error": (c_char_p, [c_void_p]),
+    "pt_upload_scene": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
+    "pt_set_camera": (c_int, [c_void_p, c_void_p]),
+    "pt_render_frame": (c_int, [c_void_p, c_void_p]),
+    "pt_render": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32]),
+    "pt_sync": (c_int, [c_void_p]),
+    "pt_read_framebuffer": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "pt_clear_framebuffer": (c_int, [c_void_p]),
+    "pt_framebuffer_device": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "pt_trace_closest": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pt_trace_closest_device": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
+    "pt_get_counters": (c_int, [c_void_p, POINTER(pt_counters)]),
+    "pt_reset_counters": (c_int, [c_void_p]),
+    "pt_partition_count": (c_uint32, [c_uint32, c_uint32, c_uint32, c_uint32, c_uint32]),
+    "pt_partition_pixels": (c_int, [c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]),
+    "pt_pack_owned": (c_int, [c_void_p, c_void_p]),
+    "pt_unpack_from": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32]),
+    "pt_debug_eval": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "pt_debug_read_queue": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32)]),
+    # host side
+    "pth_pack_half2x16": (c_uint32, [c_float, c_float]),
+    "pth_oct_encode": (None, [c_void_p, c_void_p]),
+    "pth_pack_triangle": (None, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p]),
+    "pth_pack_material": (None, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p]),
+    "pth_pack_sphere": (None, [c_void_p, c_float, c_uint32, c_void_p]),
+    "pth_pack_camera": (None, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p]),
+    "pth_build_bvh": (c_uint32, [c_void_p, c_uint32, c_void_p, c_void_p]),
+    "pth_find_emissive_tris": (c_uint32, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
+    "pth_find_emissive_spheres": (c_uint32, [c_void_p, c_uint32, c_void_p, c_uint32, c_void_p]),
+    "pth_frame_seeds": (None, [c_uint32, c_uint32, c_void_p]),
+    "pth_scene_create": (c_void_p, []),
+    "pth_scene_destroy": (None, [c_void_p]),
+    "pth_scene_add_material": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int]),
+    "pth_scene_add_sphere": (c_int, [c_void_p, c_void_p, c_float, c_uint32]),
+    "pth_scene_add_triangles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    "pth_scene_finalize": (c_int, [c_void_p]),
+    "pth_scene_desc": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
+    "pth_scene_hash": (c_uint64, [c_void_p]),
+    "pth_scene_make_cornell": (c_int, [c_void_p, c_uint32]),
+    "pth_scene_make_bunny": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_float, c_uint32]),
+    "pth_scene_make_soup": (c_int, [c_void_p, c_uint32, c_uint32, c_float]),
+    "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libpt355.so once.  torch is imported first when available so that the HIP runtime the
+    library binds to is the one torch (and RCCL) already loaded -- two HIP runtimes in one process
+    cannot share device pointers."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PtError(f"{LIB_PATH} is missing: build it with `make -C pathtracer_amd/csrc` "
+                      "(or python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
+    if os.environ.get("PT355_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in EXPORTS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(c_void_p)
+
+
+def frame_seeds(first: int, n: int) -> np.ndarray:
+    """pcg32_random() outputs number first..first+n-1 of the default global stream (src/main.cpp:97)."""
+    out = np.zeros(n, np.uint32)
+    lib().pth_frame_seeds(first, n, _ptr(out))
+    return out
+
+
+def default_camera() -> np.ndarray:
+    """Camera of src/main.cpp:67 as CameraGLSL (12 floats)."""
+    cam = np.zeros(12, np.float32)
+    o = np.zeros(3, np.float32)
+    f = np.array([0, 0, -1], np.float32)
+    r = np.array([1, 0, 0], np.float32)
+    lib().pth_pack_camera(_ptr(o), _ptr(f), _ptr(r), 0.005, 0.05, _ptr(cam))
+    return cam
+
+
+class Scene:
+    """Host-side scene container (src/main.cpp:18-63): triangles, materials, spheres -> six arrays."""
+
+    def __init__(self):
+        self._h = lib().pth_scene_create()
+        self._keep = []
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().pth_scene_destroy(self._h)
+            self._h = None
+
+    @classmethod
+    def cornell(cls, spheres: bool = False) -> "Scene":
+        s = cls()
+        _check_host(lib().pth_scene_make_cornell(s._h, 1 if spheres else 0), "pth_scene_make_cornell")
+        return s
+
+    @classmethod
+    def bunny(cls, freq: int = 59, target_tris: int = 69451, seed: int = 1, material: int = MAT_OREN_NAYAR,
+              roughness: float = 0.175, spheres: bool = False) -> "Scene":
+        s = cls()
+        _check_host(lib().pth_scene_make_bunny(s._h, freq, target_tris, seed, material, roughness, 1 if spheres else 0),
+                    "pth_scene_make_bunny")
+        return s
+
+    @classmethod
+    def soup(cls, n_tris: int, seed: int = 7, size: float = 0.25) -> "Scene":
+        s = cls()
+        _check_host(lib().pth_scene_make_soup(s._h, n_tris, seed, size), "pth_scene_make_soup")
+        return s
+
+    def add_material(self, diffuse, specular, le, roughness=0.0, tex_index=-1, mat_type=MAT_LAMBERTIAN) -> int:
+        d, s, l = (np.asarray(x, np.float32) for x in (diffuse, specular, le))
+        return lib().pth_scene_add_material(self._h, _ptr(d), _ptr(s), _ptr(l), roughness, tex_index, mat_type)
+
+    def add_sphere(self, origin, radius, mat_index) -> int:
+        o = np.asarray(origin, np.float32)
+        return lib().pth_scene_add_sphere(self._h, _ptr(o), radius, mat_index)
+
+    def add_triangles(self, v, n, mat, uv=None):
+        v = np.ascontiguousarray(v, np.float32).reshape(-1, 9)
+        n = np.ascontiguousarray(n, np.float32).reshape(-1, 9)
+        mat = np.ascontiguousarray(mat, np.uint32).reshape(-1)
+        uvp = None if uv is None else np.ascontiguousarray(uv, np.float32).reshape(-1, 6)
+        _check_host(lib().pth_scene_add_triangles(self._h, _ptr(v), _ptr(n), _ptr(uvp), _ptr(mat), v.shape[0]),
+                    "pth_scene_add_triangles")
+
+    def finalize(self):
+        _check_host(lib().pth_scene_finalize(self._h), "pth_scene_finalize")
+
+    def desc(self) -> pt_scene_desc:
+        d = pt_scene_desc()
+        _check_host(lib().pth_scene_desc(self._h, byref(d)), "pth_scene_desc")
+        return d
+
+    def hash(self) -> int:
+        return lib().pth_scene_hash(self._h)
+
+    def arrays(self) -> dict:
+        """Copies of the six arrays as numpy (u32 views of the raw records)."""
+        d = self.desc()
+
+        def grab(ptr, n, words):
+            if not ptr or n == 0:
+                return np.zeros((0, words), np.uint32)
+            return np.ctypeslib.as_array(ctypes.cast(ptr, POINTER(c_uint32)), shape=(n, words)).copy()
+
+        return {"spheres": grab(d.spheres, d.n_spheres, 8), "tris": grab(d.tris, d.n_tris, 16),
+                "light_tris": grab(d.light_tris, d.n_light_tris, 1).reshape(-1),
+                "materials": grab(d.materials, d.n_materials, 12), "nodes": grab(d.nodes, d.n_nodes, 8),
+                "light_spheres": grab(d.light_spheres, d.n_light_spheres, 1).reshape(-1)}
+
+
+def _check_host(rc, what):
+    if rc != 0:
+        raise PtError(f"{what} failed with code {rc}")
+
+
+class PathTracer:
+    """One pt_ctx: the replacement for the reference's GL upload + glDispatchCompute sequence."""
+
+    def __init__(self, width: int, height: int, device: int = 0, flags: int = 0, partition: int = PT_PARTITION_FULL,
+                 rank: int = 0, world: int = 1):
+        L = lib()
+        cfg = pt_config(width=width, height=height, device=device, flags=flags, partition=partition, rank=rank, world=world)
+        h = c_void_p()
+        rc = L.pt_create(byref(cfg), byref(h))
+        if rc != 0:
+            raise PtError(f"pt_create: {L.pt_last_error(None).decode()}")
+        self._h = h
+        self.width, self.height = width, height
+        self.rank, self.world, self.partition = rank, world, partition
+        self._scene = None
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtError(f"{what}: {lib().pt_last_error(self._h).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_scene(self, scene, env_rgb8: np.ndarray | None = None, tex_rgb8: np.ndarray | None = None):
+        d = scene.desc() if isinstance(scene, Scene) else scene
+        keep = [scene]
+        if env_rgb8 is not None:
+            env = np.ascontiguousarray(env_rgb8, np.uint8)
+            d.env_rgb8, d.env_h, d.env_w = env.ctypes.data, env.shape[0], env.shape[1]
+            keep.append(env)
+        if tex_rgb8 is not None:
+            tex = np.ascontiguousarray(tex_rgb8, np.uint8)
+            d.tex_rgb8, d.tex_layers = tex.ctypes.data, tex.shape[0]
+            keep.append(tex)
+        self._check(lib().pt_upload_scene(self._h, byref(d)), "pt_upload_scene")
+        self._scene = keep
+
+    def set_camera(self, cam12):
+        cam = np.ascontiguousarray(cam12, np.float32).reshape(12)
+        self._check(lib().pt_set_camera(self._h, _ptr(cam)), "pt_set_camera")
+
+    def render_frame(self, seed: int, frame: int, bounces: int = 5):
+        fd = np.array([seed, frame, bounces, 0], np.uint32)
+        self._check(lib().pt_render_frame(self._h, _ptr(fd)), "pt_render_frame")
+
+    def render(self, first_frame: int, seeds, bounces: int = 5):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        self._check(lib().pt_render(self._h, first_frame, seeds.size, _ptr(seeds), bounces), "pt_render")
+
+    def sync(self):
+        self._check(lib().pt_sync(self._h), "pt_sync")
+
+    def read_framebuffer(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib().pt_read_framebuffer(self._h, _ptr(out), out.size), "pt_read_framebuffer")
+        return out
+
+    def clear_framebuffer(self):
+        self._check(lib().pt_clear_framebuffer(self._h), "pt_clear_framebuffer")
+
+    def framebuffer_device(self) -> int:
+        p = c_void_p()
+        self._check(lib().pt_framebuffer_device(self._h, byref(p)), "pt_framebuffer_device")
+        return p.value
+
+    def trace_closest(self, ro, rd):
+        ro = np.ascontiguousarray(ro, np.float32).reshape(-1, 3)
+        rd = np.ascontiguousarray(rd, np.float32).reshape(-1, 3)
+        n = ro.shape[0]
+        prim = np.zeros(n, np.uint32)
+        t_h = np.zeros(n, np.uint16)
+        kind = np.zeros(n, np.uint8)
+        uv = np.zeros((n, 2), np.float32)
+        self._check(lib().pt_trace_closest(self._h, _ptr(ro), _ptr(rd), n, _ptr(prim), _ptr(t_h), _ptr(kind), _ptr(uv)),
+                    "pt_trace_closest")
+        return prim, t_h, kind, uv
+
+    def trace_closest_device(self, ray6_ptr: int, n: int, hit4_ptr: int):
+        self._check(lib().pt_trace_closest_device(self._h, c_void_p(ray6_ptr), n, c_void_p(hit4_ptr)), "pt_trace_closest_device")
+
+    def counters(self) -> dict:
+        c = pt_counters()
+        self._check(lib().pt_get_counters(self._h, byref(c)), "pt_get_counters")
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(lib().pt_reset_counters(self._h), "pt_reset_counters")
+
+    def pack_owned(self, dst_ptr: int):
+        self._check(lib().pt_pack_owned(self._h, c_void_p(dst_ptr)), "pt_pack_owned")
+
+    def unpack_from(self, src_ptr: int, from_rank: int, world: int):
+        self._check(lib().pt_unpack_from(self._h, c_void_p(src_ptr), from_rank, world), "pt_unpack_from")
+
+    def debug_read_queue(self, queue: int, field: int) -> np.ndarray:
+        cols = [1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4][field]
+        stride = ((lib().pt_partition_count(self.width, self.height, self.partition, self.rank, self.world) + 255) // 256) * 256
+        out = np.zeros((cols, max(stride, 256)), np.uint32)
+        st, cnt = c_uint32(), c_uint32()
+        self._check(lib().pt_debug_read_queue(self._h, queue, field, _ptr(out), out.size, byref(st), byref(cnt)), "pt_debug_read_queue")
+        return out, cnt.value
+
+    def debug_eval(self, op: int, a, b=None) -> np.ndarray:
+        a = np.ascontiguousarray(a, np.float32)
+        bb = None if b is None else np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(a)
+        self._check(lib().pt_debug_eval(self._h, op, _ptr(a), _ptr(bb), a.size, _ptr(out)), "pt_debug_eval")
+        return out
+
+
+def partition_pixels(width: int, height: int, partition: int, rank: int, world: int) -> np.ndarray:
+    n = lib().pt_partition_count(width, height, partition, rank, world)
+    out = np.zeros(n, np.uint32)
+    if n:
+        _check_host(lib().pt_partition_pixels(width, height, partition, rank, world, _ptr(out)), "pt_partition_pixels")
+    return out
+
+
+def tonemap_rgb8(rgba: np.ndarray) -> np.ndarray:
+    rgba = np.ascontiguousarray(rgba, np.float32)
+    h, w = rgba.shape[:2]
+    out = np.zeros((h, w, 3), np.uint8)
+    _check_host(lib().pth_tonemap_rgb8(_ptr(rgba), w, h, _ptr(out)), "pth_tonemap_rgb8")
+    return out

@@ -1,0 +1,653 @@
+// Wavefront stages around k_trace: camera rays, MIS shading (estimator_path_tracing_mis of
+// shaders/framebuffer.comp:874-1081 cut at its three intersect() calls), running-mean accumulation.
+//
+// A path lives in exactly one slot of the current queue; every per-path quantity is a structure-of-
+// arrays column indexed by that slot, so all queue traffic is coalesced.  A shading launch reads queue
+// `in`, and lanes whose path continues claim a slot of queue `out` with one atomic per wave
+// (ballot + mbcnt prefix).  Paths that end blend straight into the RGBA32F image: a pixel carries at
+// most one path per frame, so no atomics are needed there.
+#pragma once
+#include "kernels_trace.h"
+
+#define PT_SHADE_BLOCK 256
+
+// columns of one path queue; every array has `stride` entries per component
+struct PathQ {
+	uint32_t *pix;   // pixel index y*W+x
+	uint32_t *rng;   // PCG state
+	uint32_t *meta;  // bit0: shadow ray present, bit1: can_use_NEE at x, bit2: material at x is SPECULAR_METAL
+	float *thr;      // 3: throughput_term
+	float *col;      // 3: color so far
+	float *ray;      // 6: bounce ray ro, rd                                      (trace segment 0)
+	float *sray;     // 6: shadow ray origin x, direction                         (trace segment 1)
+	float *nee;      // 8: P = Le*BRDF*cos_x (3), A = pdf_light_area*d^2, pdf_BSDF(nee), y_nee (3)
+	float *bs;       // 5: BRDF (3), cos_theta_x, pdf_BSDF_sa of the sampled direction
+	uint32_t *hit;   // 4: closest hit of the bounce ray  (prim, t_h|kind<<16, u, v)
+	uint32_t *shit;  // 4: closest hit of the shadow ray
+};
+
+struct ShadeArgs {
+	DevScene sc;
+	PathQ in, out;
+	uint32_t stride;
+	DevCtl *ctl;
+	uint32_t in_q;          // index of `in` in ctl->qcount
+	float cam[12];
+	uint32_t width, height;
+	uint32_t seed, frame, bounces;
+	uint32_t stage;         // 0: after the primary trace; k: after the trace of bounce k
+	uint32_t flags;
+	float *fb;
+	// partition (raygen only)
+	uint32_t rank, world, partition, n_paths;
+};
+
+struct HitRec { // HitData, fc:214-222, members widened to float where they are float16_t
+	float t; v3 n; uint32_t mat, obj16, type; float uvx, uvy;
+};
+
+// fc:203-210
+PT_DEV v3 oct_decode(uint32_t packed)
+{
+	float x = (float) h_from_bits(packed & 0xffffu), y = (float) h_from_bits(packed >> 16);
+	float z = q16((1.0f - __builtin_fabsf(x)) - __builtin_fabsf(y));
+	float t = fmax_(-z, 0.0f);
+	x = q16(x + (x >= 0.0f ? -t : t));
+	y = q16(y + (y >= 0.0f ? -t : t));
+	return q16(normalize(V(x, y, z)));
+}
+
+// the accept block of intersect_triangle (fc:294-310) and the sphere branch of intersect (fc:447-451),
+// re-evaluated for the one hit the traversal kept.  ro, rd: the full-precision ray.
+PT_DEV HitRec hit_attributes(const DevScene &sc, uint32_t prim, uint32_t tk, float u, float v, v3 ro, v3 rd)
+{
+	HitRec h;
+	h.t = (float) h_from_bits(tk & 0xffffu);
+	h.uvx = 0.0f; h.uvy = 0.0f;
+	if ((tk >> 16) == 1u) {
+		const float4 *tp = sc.tris + 4u * (size_t) prim;
+		const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
+		const uint4 d4 = *(const uint4 *) (tp + 3);
+		const v3 v0 = V(d1.x, d1.y, d1.z);
+		const v3 e1 = V(d2.x, d2.y, d2.z) - v0;
+		const v3 e2 = V(d3.x, d3.y, d3.z) - v0;
+		const v3 n0 = oct_decode(d4.x), n1 = oct_decode(d4.y), n2 = oct_decode(d4.z);
+		h.mat = d4.w & 0xffu;
+		h.obj16 = prim & 0xffffu;
+		h.type = 0;
+		const float w = q16((1.0f - u) - v), uh = q16(u), vh = q16(v);
+		const uint32_t p0 = __float_as_uint(d1.w), p1 = __float_as_uint(d2.w), p2 = __float_as_uint(d3.w);
+		h.uvx = q16(q16(q16(w * (float) h_from_bits(p0 & 0xffffu)) + q16(uh * (float) h_from_bits(p1 & 0xffffu))) +
+		            q16(vh * (float) h_from_bits(p2 & 0xffffu)));
+		h.uvy = q16(q16(q16(w * (float) h_from_bits(p0 >> 16)) + q16(uh * (float) h_from_bits(p1 >> 16))) +
+		            q16(vh * (float) h_from_bits(p2 >> 16)));
+		const v3 sn = normalize(cross(e1, e2));
+		const v3 wn0 = V(q16(w * n0.x), q16(w * n0.y), q16(w * n0.z));
+		const v3 nn = normalize((wn0 + u * n1) + v * n2);
+		const float sgn = dot(sn, q16(rd)) < 0.0f ? 1.0f : -1.0f;
+		h.n = V(q16(q16(nn.x) * sgn), q16(q16(nn.y) * sgn), q16(q16(nn.z) * sgn));
+	} else {
+		const float4 s = sc.spheres[2u * prim];
+		const uint4 sm = *(const uint4 *) (sc.spheres + 2u * prim + 1);
+		h.n = q16(((ro + rd * h.t) - V(s.x, s.y, s.z)) / s.w);
+		h.mat = sm.x & 0xffu;
+		h.obj16 = prim & 0xffffu;
+		h.type = 1;
+	}
+	return h;
+}
+
+struct MatRec { float4 d1, d2, d3; };
+PT_DEV MatRec load_mat(const DevScene &sc, uint32_t i)
+{
+	MatRec m;
+	if (i >= sc.n_mats) i = 0;
+	m.d1 = sc.mats[3u * i]; m.d2 = sc.mats[3u * i + 1]; m.d3 = sc.mats[3u * i + 2];
+	return m;
+}
+
+// fc:141-152 transposed (fc:907)
+PT_DEV m3 tnb_rows(v3 n)
+{
+	float s = n.z < 0.0f ? -1.0f : 1.0f;
+	float a = -1.0f / (s + n.z);
+	float b = n.x * n.y * a;
+	m3 m;
+	m.r0 = V(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+	m.r1 = n;
+	m.r2 = V(b, s + n.y * n.y * a, -n.y);
+	return m;
+}
+
+// fc:154-170
+PT_DEV v3 map_to_unit_sphere(float vx, float vy)
+{
+	float cos_theta = 2.0f * vx - 1.0f;
+	float phi = PT_TWO_PI * vy;
+	float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+	float sp, cp;
+	ptm_sincos(phi, &sp, &cp);
+	return V(sin_theta * cp, cos_theta, sin_theta * sp);
+}
+
+// fc:180-184
+PT_DEV void cartesian_to_spherical(v3 vec, float *theta, float *phi)
+{
+	*theta = ptm_acos(vec.y);
+	*phi = ptm_atan2(vec.x, vec.z) + PT_PI;
+}
+
+PT_DEV v3 texel_rgb8_h(const uint8_t *img, uint32_t w, uint32_t h, int x, int y)
+{
+	x = x < 0 ? 0 : (x >= (int) w ? (int) w - 1 : x);
+	y = y < 0 ? 0 : (y >= (int) h ? (int) h - 1 : y);
+	const uint8_t *p = img + ((size_t) y * w + (size_t) x) * 3;
+	return V(q16((float) p[0] / 255.0f), q16((float) p[1] / 255.0f), q16((float) p[2] / 255.0f));
+}
+
+// fc:186-201 over an RGB8 image stored as RGB16F, GL_LINEAR + CLAMP_TO_EDGE (src/display/display.cpp:174-189)
+PT_DEV v3 sky_color(const DevScene &sc, v3 dir)
+{
+	if (!sc.env || sc.env_w == 0 || sc.env_h == 0) return V(0.0f, 0.0f, 0.0f);
+	float theta, phi;
+	cartesian_to_spherical(dir, &theta, &phi);
+	phi += PT_PI / 8.0f;
+	if (phi < 0.0f) phi += PT_TWO_PI;
+	if (phi > PT_TWO_PI) phi -= PT_TWO_PI;
+	const float s = phi / PT_TWO_PI, t = theta / PT_PI;
+	const float x = s * (float) sc.env_w - 0.5f, y = t * (float) sc.env_h - 0.5f;
+	const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+	const float ax = x - fx, ay = y - fy;
+	const int x0 = (int) fx, y0 = (int) fy;
+	const v3 c00 = texel_rgb8_h(sc.env, sc.env_w, sc.env_h, x0, y0), c10 = texel_rgb8_h(sc.env, sc.env_w, sc.env_h, x0 + 1, y0);
+	const v3 c01 = texel_rgb8_h(sc.env, sc.env_w, sc.env_h, x0, y0 + 1), c11 = texel_rgb8_h(sc.env, sc.env_w, sc.env_h, x0 + 1, y0 + 1);
+	const v3 top = c00 * (1.0f - ax) + c10 * ax;
+	const v3 bot = c01 * (1.0f - ax) + c11 * ax;
+	return q16(top * (1.0f - ay) + bot * ay);
+}
+
+// sampler2DArray, 512x512 RGB8, GL_REPEAT + GL_LINEAR, level 0 (src/loader.cpp:50-58)
+PT_DEV v3 sample_texture(const DevScene &sc, float u, float v, float layer)
+{
+	if (!sc.tex || sc.tex_layers == 0) return V(0.0f, 0.0f, 0.0f);
+	int l = (int) __builtin_floorf(layer + 0.5f);
+	l = l < 0 ? 0 : (l >= (int) sc.tex_layers ? (int) sc.tex_layers - 1 : l);
+	const uint8_t *img = sc.tex + (size_t) l * 512 * 512 * 3;
+	const float x = u * 512.0f - 0.5f, y = v * 512.0f - 0.5f;
+	const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+	const float ax = x - fx, ay = y - fy;
+	const int x0 = ((int) fx % 512 + 512) % 512, y0 = ((int) fy % 512 + 512) % 512;
+	const int x1 = (x0 + 1) % 512, y1 = (y0 + 1) % 512;
+	auto tx = [&](int xx, int yy) {
+		const uint8_t *p = img + ((size_t) yy * 512 + (size_t) xx) * 3;
+		return V((float) p[0] / 255.0f, (float) p[1] / 255.0f, (float) p[2] / 255.0f);
+	};
+	const v3 top = tx(x0, y0) * (1.0f - ax) + tx(x1, y0) * ax;
+	const v3 bot = tx(x0, y1) * (1.0f - ax) + tx(x1, y1) * ax;
+	return top * (1.0f - ay) + bot * ay;
+}
+
+// fc:458-472
+PT_DEV v3 oren_nayar_brdf(v3 albedo, float roughness, v3 wi, v3 wo)
+{
+	float theta_i, phi_i, theta_o, phi_o;
+	cartesian_to_spherical(wi, &theta_i, &phi_i);
+	cartesian_to_spherical(wo, &theta_o, &phi_o);
+	float sq = roughness * roughness;
+	float A = 1.0f - 0.5f * sq / (sq + 0.33f);
+	float B = 0.45f * sq / (sq + 0.09f);
+	float alpha = fmax_(theta_i, theta_o);
+	float beta = fmin_(theta_i, theta_o);
+	float k = A + B * fmax_(0.0f, ptm_cos(phi_i - phi_o)) * ptm_sin(alpha) * ptm_tan(beta);
+	return (albedo / PT_PI) * k;
+}
+
+PT_DEV float chi_plus(float v) { return v > 0.0f ? 1.0f : 0.0f; }
+// fc:505-514
+PT_DEV float ggx_ndf(v3 wm, v3 wg, float alpha_ggx)
+{
+	float d = dot(wg, wm);
+	float sa = fmax_(PT_EPSILON * 10.0f, alpha_ggx * alpha_ggx);
+	float inner = 1.0f + d * d * (sa - 1.0f);
+	float denominator = PT_PI * (inner * inner);
+	return chi_plus(d) * sa / denominator;
+}
+// fc:517-524
+PT_DEV float ggx_lambda(v3 dir, float alpha_ggx)
+{
+	float cos_theta = dir.y;
+	float sin_theta_2 = fmax_(0.0f, 1.0f - cos_theta * cos_theta);
+	float tan_theta = __builtin_sqrtf(sin_theta_2) / cos_theta;
+	float a = 1.0f / (alpha_ggx * tan_theta);
+	return -0.5f + 0.5f * __builtin_sqrtf(1.0f + 1.0f / (a * a));
+}
+// fc:527-532
+PT_DEV float ggx_g2(v3 wi, v3 wo, v3 wm, float alpha_ggx)
+{
+	float result = chi_plus(dot(wm, wo)) * chi_plus(dot(wm, wi));
+	result /= (1.0f + ggx_lambda(wo, alpha_ggx) + ggx_lambda(wi, alpha_ggx));
+	return result;
+}
+// fc:535-538
+PT_DEV v3 fresnel(v3 wm, v3 wi, v3 F0)
+{
+	float x = 1.0f - fmin_(1.0f, fmax_(0.0f, dot(wm, wi)));
+	float x2 = x * x;
+	float p = x2 * x2 * x;
+	return F0 + (V(1.0f, 1.0f, 1.0f) - F0) * p;
+}
+// fc:540-549
+PT_DEV v3 ggx_brdf_non_is(v3 wo, v3 wi, v3 F0, float alpha_ggx)
+{
+	v3 wg = V(0.0f, 1.0f, 0.0f);
+	v3 wm = normalize(wo + wi);
+	v3 result = fresnel(wm, wi, F0) * ggx_g2(wi, wo, wm, alpha_ggx) * ggx_ndf(wm, wg, alpha_ggx);
+	return result / fmax_(PT_EPSILON * 10.0f, 4.0f * __builtin_fabsf(dot(wg, wi)) * __builtin_fabsf(dot(wg, wo)));
+}
+// fc:551-560
+PT_DEV v3 ggx_brdf_is(v3 wo, v3 wm, v3 wi, v3 F0, float alpha_ggx)
+{
+	v3 wg = V(0.0f, 1.0f, 0.0f);
+	v3 result = fresnel(wm, wi, F0) * ggx_g2(wi, wo, wm, alpha_ggx) * __builtin_fabsf(dot(wo, wm));
+	return result / fmax_(PT_EPSILON * 10.0f, __builtin_fabsf(dot(wg, wo)) * __builtin_fabsf(dot(wg, wm)));
+}
+
+// fc:591-643
+PT_DEV v3 calc_brdf(const DevScene &sc, v3 wo, v3 wm, v3 wi, const MatRec &mat, float uvx, float uvy, bool using_nee)
+{
+	v3 brdf = V(1.0f, 1.0f, 0.0f);
+	const int mat_type = (int) mat.d2.w;
+	v3 albedo = V(mat.d1.x, mat.d1.y, mat.d1.z);
+	v3 F0 = V(mat.d2.x, mat.d2.y, mat.d2.z);
+	v3 diffuse_texture = V(0.0f, 0.0f, 0.0f);
+	if (mat.d3.w > -1.0f) {
+		diffuse_texture = sample_texture(sc, uvx, uvy, mat.d3.w);
+		albedo = albedo * diffuse_texture;
+	}
+	if (mat_type == -1) brdf = V(0.0f, 0.0f, 0.0f);
+	if (mat_type == 1) brdf = oren_nayar_brdf(albedo, mat.d1.w, wi, wo);
+	if (mat_type == 0) brdf = albedo / PT_PI;
+	if (mat_type == 2) {
+		if (mat.d3.w > -1.0f) F0 = F0 * diffuse_texture;
+		if (!using_nee) brdf = ggx_brdf_is(wo, wm, wi, F0, mat.d1.w);
+		else brdf = ggx_brdf_non_is(wo, wi, F0, mat.d1.w);
+	}
+	return brdf;
+}
+
+// fc:695-700
+PT_DEV float area_triangle(const DevScene &sc, uint32_t i)
+{
+	if (i >= sc.n_tris) i = 0;
+	const float4 *tp = sc.tris + 4u * (size_t) i;
+	const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
+	const v3 v0 = V(d1.x, d1.y, d1.z);
+	const v3 e1 = V(d2.x, d2.y, d2.z) - v0, e2 = V(d3.x, d3.y, d3.z) - v0;
+	return __builtin_sqrtf(dot(e1, e1) * dot(e2, e2)) * 0.5f;
+}
+PT_DEV float area_sphere(float r) { return 4.0f * PT_PI * r * r; }
+
+PT_DEV v3 ld3(const float *p, uint32_t i, uint32_t st) { return V(p[i], p[st + i], p[2 * st + i]); }
+PT_DEV void st3(float *p, uint32_t i, uint32_t st, v3 v) { p[i] = v.x; p[st + i] = v.y; p[2 * st + i] = v.z; }
+
+// tile-major path -> pixel map shared with pt_partition_pixels(): path p of this rank is pixel
+// (p % 64) of its (p / 64)-th own 8x8 tile; with PT_PARTITION_TILES tile t belongs to rank t % world.
+PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t tiles_x = width >> 3;
+	uint32_t tile = p >> 6;
+	if (partition == 0u && world > 1u) tile = tile * world + rank;
+	const uint32_t in = p & 63u;
+	const uint32_t x = (tile % tiles_x) * 8u + (in & 7u), y = (tile / tiles_x) * 8u + (in >> 3);
+	return y * width + x;
+}
+
+// main() + render_function(), fc:1088-1122: seed, pixel jitter, pinhole ray.
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p == 0) {
+		a.ctl->qcount[0] = a.n_paths;
+		a.ctl->qcount[1] = 0;
+		a.ctl->work = 0;
+		atomicAdd(&a.ctl->paths, (unsigned long long) a.n_paths);
+		atomicAdd(&a.ctl->rays_primary, (unsigned long long) a.n_paths);
+	}
+	if (p >= a.n_paths) return;
+	const uint32_t pixel = path_pixel(p, a.width, a.partition, a.rank, a.world);
+	const uint32_t px = pixel % a.width, py = pixel / a.width;
+	uint32_t rng = seed3(px, py, a.seed);
+
+	const v3 cam_origin = V(a.cam[0], a.cam[1], a.cam[2]);
+	const v3 cam_forward = V(a.cam[4], a.cam[5], a.cam[6]);
+	const v3 cam_right = V(a.cam[8], a.cam[9], a.cam[10]);
+	const float sw = (float) a.width, sh = (float) a.height;
+	const float grid_height = 2.0f;
+	const float grid_width = grid_height * sw / sh;
+	const v3 cam_up = normalize(cross(cam_right, cam_forward));
+	const v3 grid_x = cam_right * grid_width;
+	const v3 grid_y = cam_up * grid_height;
+	v3 grid_origin = (cam_origin - (grid_x * 0.5f)) - (grid_y * 0.5f);
+	grid_origin = grid_origin + 2.0f * cam_forward;
+	const float ox = rnd(rng) - 0.5f;
+	const float oy = rnd(rng) - 0.5f;
+	const float u = ((float) (int) px + ox) / sw;
+	const float v = ((float) (int) py + oy) / sh;
+	const v3 point_on_grid = (grid_origin + u * grid_x) + v * grid_y;
+	const v3 rd = normalize(point_on_grid - cam_origin);
+
+	const uint32_t st = a.stride;
+	a.out.pix[p] = pixel;
+	a.out.rng[p] = rng;
+	a.out.meta[p] = 0;
+	st3(a.out.thr, p, st, V(1.0f, 1.0f, 1.0f));
+	st3(a.out.col, p, st, V(0.0f, 0.0f, 0.0f));
+	st3(a.out.ray, p, st, cam_origin);
+	st3(a.out.ray + 3 * (size_t) st, p, st, rd);
+}
+
+// fc:1124-1129
+PT_DEV void accumulate(const ShadeArgs &a, uint32_t pixel, v3 color)
+{
+	float4 *px = (float4 *) a.fb + pixel;
+	const float4 last = *px;
+	const float fa = (float) a.frame / (float) (a.frame + 1u), fb = 1.0f / (float) (a.frame + 1u);
+	float4 o;
+	o.x = fa * last.x + fb * color.x;
+	o.y = fa * last.y + fb * color.y;
+	o.z = fa * last.z + fb * color.z;
+	o.w = 1.0f;
+	*px = o;
+}
+
+// One shading stage.  stage 0 consumes the primary hit (fc:880-896); stage k >= 1 consumes the shadow and
+// bounce hits of bounce k (fc:970-1077) and, unless k == bounces, emits bounce k+1 (fc:901-968, 1009-1017).
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t n_in = a.ctl->qcount[a.in_q];
+	if (i == 0) a.ctl->work = 0;
+	const uint32_t st = a.stride;
+	const DevScene &sc = a.sc;
+	bool alive = i < n_in;
+
+	uint32_t pixel = 0, rng = 0, meta = 0;
+	v3 thr = V(0, 0, 0), col = V(0, 0, 0), ro = V(0, 0, 0), rd = V(0, 0, 0);
+	HitRec data;
+	data.t = 0; data.n = V(0, 0, 0); data.mat = 0; data.obj16 = 0; data.type = 0; data.uvx = 0; data.uvy = 0;
+	v3 y = V(0, 0, 0);
+	MatRec mat_y;
+	mat_y.d1 = mat_y.d2 = mat_y.d3 = make_float4(0, 0, 0, 0);
+	const uint32_t num_light_sources = sc.n_light_tris + sc.n_light_spheres;
+
+	if (alive) {
+		pixel = a.in.pix[i]; rng = a.in.rng[i]; meta = a.in.meta[i];
+		thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
+		ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
+		const uint32_t hp = a.in.hit[i], htk = a.in.hit[st + i];
+		const float hu = __uint_as_float(a.in.hit[2 * st + i]), hv = __uint_as_float(a.in.hit[3 * st + i]);
+		const bool hit_anything = (htk >> 16) != 0u;
+
+		if (a.stage == 0) {
+			if (!hit_anything) {
+				col = sky_color(sc, rd) * 1.0f; // fc:884
+				accumulate(a, pixel, col);
+				alive = false;
+			} else {
+				data = hit_attributes(sc, hp, htk, hu, hv, ro, rd);
+				y = (ro + rd * data.t) + PT_NORMAL_OFFSET * data.n; // fc:887
+				mat_y = load_mat(sc, data.mat);
+				col = col + V(mat_y.d3.x, mat_y.d3.y, mat_y.d3.z);   // fc:894
+			}
+		} else {
+			const bool can_use_nee = (meta & 2u) != 0u;
+			// ---- NEE of this bounce, resolved now that the shadow ray is back (fc:970-1006)
+			if (meta & 1u) {
+				v3 direct = V(0.0f, 0.0f, 0.0f);
+				const uint32_t sp_ = a.in.shit[i], stk = a.in.shit[st + i];
+				if ((stk >> 16) != 0u) {
+					const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
+					const float su = __uint_as_float(a.in.shit[2 * st + i]), sv = __uint_as_float(a.in.shit[3 * st + i]);
+					const HitRec sh = hit_attributes(sc, sp_, stk, su, sv, sro, srd);
+					const v3 y_nee = ld3(a.in.nee + 5 * (size_t) st, i, st);
+					const v3 dlt = y_nee - (sro + srd * sh.t);
+					if (dlt.x < PT_FLOAT_COMPARE && dlt.y < PT_FLOAT_COMPARE && dlt.z < PT_FLOAT_COMPARE) {
+						const float cos_theta_y = dot(sh.n, -srd);
+						if (cos_theta_y > 0.0f) {
+							const v3 P = ld3(a.in.nee, i, st);
+							const float A = a.in.nee[3 * (size_t) st + i], pdf_bsdf = a.in.nee[4 * (size_t) st + i];
+							const float pdf_nee_sa = A / cos_theta_y;
+							const float w_nee = pdf_nee_sa / (pdf_nee_sa + pdf_bsdf);
+							direct = direct + P * w_nee / pdf_nee_sa;
+						}
+					}
+				}
+				direct = direct / 1.0f;
+				col = col + thr * direct;
+			}
+			// ---- the bounce ray (fc:1023-1077)
+			const v3 brdf = ld3(a.in.bs, i, st);
+			const float cos_theta_x = a.in.bs[3 * (size_t) st + i], pdf_bsdf_sa = a.in.bs[4 * (size_t) st + i];
+			if (!hit_anything) {
+				col = col + 1.0f * thr * brdf * cos_theta_x * sky_color(sc, rd) / pdf_bsdf_sa; // fc:1027
+				accumulate(a, pixel, col);
+				alive = false;
+			} else {
+				data = hit_attributes(sc, hp, htk, hu, hv, ro, rd);
+				const float cos_theta_y = dot(data.n, -rd);
+				y = (ro + rd * data.t) + PT_NORMAL_OFFSET * data.n;
+				mat_y = load_mat(sc, data.mat);
+				const v3 le_y = V(mat_y.d3.x, mat_y.d3.y, mat_y.d3.z);
+				float w_bsdf = 1.0f;
+				if (can_use_nee && cos_theta_y > 0.0f) {
+					if (mat_y.d2.w == -1.0f) {
+						float pdf_nee_area = 0.0f;
+						if (data.type == 0u) pdf_nee_area = 1.0f / area_triangle(sc, data.obj16);
+						else if (data.type == 1u) pdf_nee_area = 1.0f / area_sphere(sc.spheres[2u * (data.obj16 < sc.n_spheres ? data.obj16 : 0u)].w);
+						pdf_nee_area /= (float) num_light_sources;
+						const float pdf_nee_sa = pdf_nee_area * data.t * data.t / cos_theta_y;
+						w_bsdf = pdf_bsdf_sa / (pdf_bsdf_sa + pdf_nee_sa);
+					}
+					col = col + thr * brdf * le_y * cos_theta_y * w_bsdf / pdf_bsdf_sa; // fc:1066
+				}
+				thr = thr * (brdf * cos_theta_x / pdf_bsdf_sa); // fc:1069
+				if (!can_use_nee && (meta & 4u)) col = col + thr * le_y; // fc:1071-1077
+				const bool dead = thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f && !(a.flags & PT_FLAG_TRACE_DEAD_PATHS);
+				if (a.stage == a.bounces || dead) {
+					accumulate(a, pixel, col);
+					alive = false;
+				}
+			}
+		}
+	}
+	if (a.stage == 0 && a.bounces == 0 && alive) { // frame_data.z == 0: the loop at fc:899 never runs
+		accumulate(a, pixel, col);
+		alive = false;
+	}
+
+	// ---- claim a slot of the next queue: one atomic per wave
+	const unsigned long long live = __ballot(alive);
+	if (live == 0ull) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t leader = (uint32_t) __builtin_ctzll(live);
+	uint32_t base = 0;
+	if (lane == leader) base = atomicAdd(&a.ctl->qcount[a.in_q ^ 1u], (uint32_t) __popcll(live));
+	base = __shfl(base, leader);
+	if (!alive) return;
+	const uint32_t o = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) live, 0u));
+
+	// ---- emit bounce b = stage + 1 from x = y (fc:901-968, 1009-1017)
+	const v3 x = y;
+	const v3 normal_x = data.n;
+	const MatRec mat_x = mat_y;
+	const float alpha_squared = mat_x.d1.w * mat_x.d1.w;
+	const m3 tnb = tnb_rows(normal_x);
+	const m3 inverse_tnb = inverse(tnb);
+	const v3 wo = normalize(mul(tnb, -rd));
+	bool can_use_nee = num_light_sources > 0u;
+	can_use_nee = can_use_nee && (mat_x.d2.w == 0.0f || mat_x.d2.w == 1.0f || (mat_x.d2.w == 2.0f && alpha_squared > 0.0f));
+	uint32_t new_meta = (can_use_nee ? 3u : 0u) | (mat_x.d2.w == 2.0f ? 4u : 0u);
+	if (can_use_nee) {
+		const float pdf_pick_light = 1.0f / (float) num_light_sources;
+		const int picked = (int) (pcg(rng) % num_light_sources);
+		float light_area = 0.0f;
+		v3 y_nee = V(0.0f, 0.0f, 0.0f);
+		v3 le = V(0.0f, 0.0f, 0.0f);
+		if (sc.n_light_tris > 0u && picked < (int) sc.n_light_tris) {
+			uint32_t li = sc.light_tris[picked];
+			if (li >= sc.n_tris) li = 0;
+			const float4 *tp = sc.tris + 4u * (size_t) li;
+			const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
+			const uint4 d4 = *(const uint4 *) (tp + 3);
+			light_area = area_triangle(sc, li);
+			const MatRec lm = load_mat(sc, d4.w);
+			le = V(lm.d3.x, lm.d3.y, lm.d3.z);
+			float r1 = rnd(rng), r2 = rnd(rng);
+			if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; } // fc:707-723
+			const v3 v0 = V(d1.x, d1.y, d1.z);
+			const v3 pnt = r1 * (V(d2.x, d2.y, d2.z) - v0) + r2 * (V(d3.x, d3.y, d3.z) - v0);
+			y_nee = pnt + v0;
+		} else if (sc.n_light_spheres > 0u) {
+			uint32_t si = sc.light_spheres[picked - (int) sc.n_light_tris];
+			if (si >= sc.n_spheres) si = 0;
+			const float4 s = sc.spheres[2u * si];
+			const uint4 sm = *(const uint4 *) (sc.spheres + 2u * si + 1);
+			light_area = area_sphere(s.w);
+			const MatRec lm = load_mat(sc, sm.x);
+			le = V(lm.d3.x, lm.d3.y, lm.d3.z);
+			const float r1 = rnd(rng), r2 = rnd(rng);
+			y_nee = map_to_unit_sphere(r1, r2) * s.w + V(s.x, s.y, s.z);
+		}
+		const v3 dist_vec = y_nee - x;
+		const v3 shadow_rd = normalize(dist_vec);
+		const float squared_dist = dot(dist_vec, dist_vec);
+		const float cos_theta_x = fmax_(0.0f, dot(normal_x, shadow_rd));
+		const v3 wi = normalize(mul(tnb, shadow_rd));
+		const v3 wm = normalize(mul(tnb, data.n));
+		const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, true);
+		const v3 P = le * brdf * cos_theta_x;
+		const float pdf_light_area = pdf_pick_light * (1.0f / light_area);
+		st3(a.out.sray, o, st, x);
+		st3(a.out.sray + 3 * (size_t) st, o, st, shadow_rd);
+		st3(a.out.nee, o, st, P);
+		a.out.nee[3 * (size_t) st + o] = pdf_light_area * squared_dist;
+		a.out.nee[4 * (size_t) st + o] = cos_theta_x / PT_PI;
+		st3(a.out.nee + 5 * (size_t) st, o, st, y_nee);
+	}
+	const v3 new_ro = x + PT_NORMAL_OFFSET * normal_x; // fc:1009
+
+	// pick_wi, fc:563-589 (using_NEE = false)
+	v3 wm = V(0.0f, 0.0f, 0.0f), wi;
+	float cos_theta_x = 0.0f, pdf_bsdf_sa = 0.0f;
+	const float ty = mat_x.d2.w;
+	if (ty == -1.0f || ty == 0.0f || ty == 1.0f) {
+		wm = V(0.0f, 1.0f, 0.0f);
+		const float r1 = rnd(rng), r2 = rnd(rng);
+		wi = normalize(map_to_unit_sphere(r1, r2) + wm);
+		cos_theta_x = dot(wm, wi);
+		pdf_bsdf_sa = cos_theta_x / PT_PI;
+	} else if (ty == 2.0f) {
+		cos_theta_x = 1.0f;
+		pdf_bsdf_sa = 1.0f;
+		const float alpha_ggx = mat_x.d1.w;
+		const float a2 = alpha_ggx * alpha_ggx;
+		const float e1 = rnd(rng), e2 = rnd(rng);
+		const float theta = ptm_acos(__builtin_sqrtf((1.0f - e1) / ((a2 - 1.0f) * e1 + 1.0f)));
+		const float phi = PT_TWO_PI * e2;
+		float s_t, c_t, s_p, c_p;
+		ptm_sincos(theta, &s_t, &c_t);
+		ptm_sincos(phi, &s_p, &c_p);
+		wm = V(s_t * c_p, c_t, s_t * s_p);
+		const v3 I = -wo;
+		wi = normalize(I - (2.0f * dot(wm, I)) * wm);
+	} else {
+		wi = V(__builtin_inff(), __builtin_inff(), __builtin_inff());
+	}
+	const v3 new_rd = normalize(mul(inverse_tnb, wi));
+	const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, false);
+
+	a.out.pix[o] = pixel;
+	a.out.rng[o] = rng;
+	a.out.meta[o] = new_meta;
+	st3(a.out.thr, o, st, thr);
+	st3(a.out.col, o, st, col);
+	st3(a.out.ray, o, st, new_ro);
+	st3(a.out.ray + 3 * (size_t) st, o, st, new_rd);
+	st3(a.out.bs, o, st, brdf);
+	a.out.bs[3 * (size_t) st + o] = cos_theta_x;
+	a.out.bs[4 * (size_t) st + o] = pdf_bsdf_sa;
+
+	// rays are counted when they are enqueued
+	const unsigned long long sh_mask = __ballot(can_use_nee);
+	if (lane == leader) {
+		atomicAdd(&a.ctl->rays_bounce, (unsigned long long) __popcll(live));
+		if (sh_mask) atomicAdd(&a.ctl->rays_shadow, (unsigned long long) __popcll(sh_mask));
+	}
+}
+
+// multi-GPU helpers: the packed order is the path order of k_raygen
+__global__ void k_pack_owned(const float4 *fb, float4 *dst, uint32_t n, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p < n) dst[p] = fb[path_pixel(p, width, partition, rank, world)];
+}
+__global__ void k_unpack_from(float4 *fb, const float4 *src, uint32_t n, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p < n) fb[path_pixel(p, width, partition, rank, world)] = src[p];
+}
+
+// numerics self-test: one primitive of the contract per launch (op codes: oracle/oracle.h)
+__global__ void k_debug_eval(int op, const float *a, const float *b, uint32_t n, float *out)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float x = a[i], y = b ? b[i] : 0.0f;
+	float r = 0.0f;
+	switch (op) {
+	case 0: r = fmin_(x, y); break;
+	case 1: r = fmax_(x, y); break;
+	case 2: r = x / y; break;
+	case 3: r = __builtin_sqrtf(x); break;
+	case 4: r = q16(x); break;
+	case 5: r = ptm_sin(x); break;
+	case 6: r = ptm_cos(x); break;
+	case 7: r = ptm_tan(x); break;
+	case 8: r = ptm_acos(x); break;
+	case 9: r = ptm_atan2(x, y); break;
+	case 10: r = (float) ((h16) x + (h16) y); break; // native fp16 add
+	case 11: r = (float) ((h16) x * (h16) y); break; // native fp16 mul
+	case 12: { uint32_t s = __float_as_uint(x); r = rnd(s); break; }
+	case 13: case 14: case 15: {
+		uint32_t s = __float_as_uint(x);
+		const v3 up = V(0.0f, 1.0f, 0.0f);
+		float r1 = rnd(s), r2 = rnd(s);
+		const v3 wo = normalize(map_to_unit_sphere(r1, r2) + up);
+		const v3 F0 = V(0.944f, 0.776f, 0.373f);
+		if (op == 13) {
+			r1 = rnd(s); r2 = rnd(s);
+			const v3 wi = normalize(map_to_unit_sphere(r1, r2) + up);
+			r = oren_nayar_brdf(V(1.0f, 0.5f, 0.25f), y, wi, wo).y;
+		} else if (op == 14) {
+			r1 = rnd(s); r2 = rnd(s);
+			const v3 wi = normalize(map_to_unit_sphere(r1, r2) + up);
+			r = ggx_brdf_non_is(wo, wi, F0, y).x;
+		} else {
+			const float a2 = y * y;
+			const float e1 = rnd(s), e2 = rnd(s);
+			const float theta = ptm_acos(__builtin_sqrtf((1.0f - e1) / ((a2 - 1.0f) * e1 + 1.0f)));
+			const float phi = PT_TWO_PI * e2;
+			float s_t, c_t, s_p, c_p;
+			ptm_sincos(theta, &s_t, &c_t);
+			ptm_sincos(phi, &s_p, &c_p);
+			const v3 wm = V(s_t * c_p, c_t, s_t * s_p);
+			const v3 I = -wo;
+			const v3 wi = normalize(I - (2.0f * dot(wm, I)) * wm);
+			r = ggx_brdf_is(wo, wm, wi, F0, y).x + wi.y;
+		}
+		break;
+	}
+	default: break;
+	}
+	out[i] = r;
+}

@@ -1,0 +1,590 @@
+// libpt355.so -- context management and the C ABI of include/pt355.h over the gfx950 kernels.
+// One context = one device, one stream, scene copies in HBM, two ping-pong path queues.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pt355.h"
+#include "kernels_shade.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t a, b; int kind; };
+
+} // namespace
+
+struct pt_ctx {
+	pt_config cfg;
+	hipStream_t stream = nullptr;
+	std::string err;
+	int n_cu = 0;
+	int trace_grid = 0;
+
+	// scene
+	DevScene sc{};
+	void *nodes_alloc = nullptr;
+	std::vector<void *> scene_allocs;
+	bool have_scene = false, have_camera = false;
+	float cam[12];
+
+	// queues
+	uint32_t n_paths = 0, stride = 0;
+	void *queue_alloc = nullptr;
+	PathQ q[2];
+	DevCtl *ctl = nullptr;
+	uint32_t *spill = nullptr;
+	float *fb = nullptr;
+
+	// timing
+	std::vector<EventPair> pending, free_events;
+	double ms_trace = 0, ms_shade = 0;
+	uint64_t trace_launches = 0, frames = 0;
+};
+
+namespace {
+
+int fail(pt_ctx *c, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf;
+	else g_create_error = buf;
+	return code;
+}
+
+#define HIP_TRY(c, call)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (call);                                                                       \
+		if (e_ != hipSuccess) return fail(c, PT_EHIP, "%s: %s", #call, hipGetErrorString(e_));        \
+	} while (0)
+
+uint32_t own_tiles(uint32_t width, uint32_t height, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t tiles = (width / 8) * (height / 8);
+	if (partition != PT_PARTITION_TILES || world <= 1) return tiles;
+	return rank < tiles ? (tiles - rank + world - 1) / world : 0;
+}
+
+uint32_t host_path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t tiles_x = width >> 3;
+	uint32_t tile = p >> 6;
+	if (partition == PT_PARTITION_TILES && world > 1) tile = tile * world + rank;
+	const uint32_t in = p & 63u;
+	return ((tile / tiles_x) * 8u + (in >> 3)) * width + (tile % tiles_x) * 8u + (in & 7u);
+}
+
+void begin_timed(pt_ctx *c, int kind)
+{
+	EventPair ev;
+	if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
+	else { hipEventCreate(&ev.a); hipEventCreate(&ev.b); }
+	ev.kind = kind;
+	hipEventRecord(ev.a, c->stream);
+	c->pending.push_back(ev);
+}
+void end_timed(pt_ctx *c) { hipEventRecord(c->pending.back().b, c->stream); }
+
+int drain_events(pt_ctx *c)
+{
+	if (c->pending.empty()) return PT_OK;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	for (EventPair &ev : c->pending) {
+		float ms = 0;
+		hipEventElapsedTime(&ms, ev.a, ev.b);
+		if (ev.kind == 0) c->ms_trace += ms; else c->ms_shade += ms;
+		c->free_events.push_back(ev);
+	}
+	c->pending.clear();
+	return PT_OK;
+}
+
+template <typename T> int upload(pt_ctx *c, const void *src, size_t bytes, T **dst, size_t pad_front = 0)
+{
+	*dst = nullptr;
+	if (bytes == 0) return PT_OK;
+	char *p = nullptr;
+	HIP_TRY(c, hipMalloc((void **) &p, bytes + pad_front + 64));
+	c->scene_allocs.push_back(p);
+	HIP_TRY(c, hipMemsetAsync(p, 0, bytes + pad_front + 64, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(p + pad_front, src, bytes, hipMemcpyHostToDevice, c->stream));
+	*dst = (T *) (p + pad_front);
+	return PT_OK;
+}
+
+void free_scene(pt_ctx *c)
+{
+	for (void *p : c->scene_allocs) hipFree(p);
+	c->scene_allocs.clear();
+	memset(&c->sc, 0, sizeof c->sc);
+	c->have_scene = false;
+}
+
+void carve_queue(PathQ &q, char *&p, uint32_t stride)
+{
+	auto take = [&](uint32_t cols) { void *r = p; p += (size_t) cols * stride * 4; return r; };
+	q.pix = (uint32_t *) take(1); q.rng = (uint32_t *) take(1); q.meta = (uint32_t *) take(1);
+	q.thr = (float *) take(3); q.col = (float *) take(3);
+	q.ray = (float *) take(6); q.sray = (float *) take(6);
+	q.nee = (float *) take(8); q.bs = (float *) take(5);
+	q.hit = (uint32_t *) take(4); q.shit = (uint32_t *) take(4);
+}
+const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
+
+int launch_trace(pt_ctx *c, const TraceArgs &ta)
+{
+	begin_timed(c, 0);
+	if (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL)
+		hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+	else
+		hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+	end_timed(c);
+	c->trace_launches++;
+	HIP_TRY(c, hipGetLastError());
+	return PT_OK;
+}
+
+TraceArgs queue_trace_args(pt_ctx *c, uint32_t qi, bool with_shadow)
+{
+	TraceArgs ta;
+	memset(&ta, 0, sizeof ta);
+	ta.sc = c->sc;
+	ta.seg[0].ray = c->q[qi].ray; ta.seg[0].hit = c->q[qi].hit; ta.seg[0].valid = nullptr;
+	ta.seg[1].ray = c->q[qi].sray; ta.seg[1].hit = c->q[qi].shit; ta.seg[1].valid = c->q[qi].meta;
+	ta.stride = c->stride;
+	ta.count_ptr = &c->ctl->qcount[qi];
+	ta.n_segs = with_shadow ? 2 : 1;
+	ta.refill_threshold = 24;
+	ta.ctl = c->ctl;
+	ta.zero_on_entry = &c->ctl->qcount[qi ^ 1u];
+	ta.spill = c->spill;
+	return ta;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *pt_last_error(const pt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int pt_create(const pt_config *cfg, pt_ctx **out)
+{
+	if (!cfg || !out) return fail(nullptr, PT_EINVAL, "pt_create: null argument");
+	*out = nullptr;
+	if (cfg->width == 0 || cfg->height == 0 || (cfg->width & 7u) || (cfg->height & 7u))
+		return fail(nullptr, PT_EINVAL, "pt_create: width and height must be positive multiples of 8 (got %ux%u)", cfg->width, cfg->height);
+	if ((uint64_t) cfg->width * cfg->height > (1ull << 28))
+		return fail(nullptr, PT_EINVAL, "pt_create: image too large");
+	if (cfg->partition > PT_PARTITION_FULL) return fail(nullptr, PT_EINVAL, "pt_create: unknown partition %u", cfg->partition);
+	const uint32_t world = cfg->world ? cfg->world : 1;
+	if (cfg->rank >= world) return fail(nullptr, PT_EINVAL, "pt_create: rank %u outside world %u", cfg->rank, world);
+	if (cfg->flags & PT_FLAG_SHADOW_ANYHIT) return fail(nullptr, PT_EINVAL, "pt_create: PT_FLAG_SHADOW_ANYHIT is not built yet");
+
+	int ndev = 0;
+	hipError_t e = hipGetDeviceCount(&ndev);
+	if (e != hipSuccess || ndev == 0)
+		return fail(nullptr, PT_EHIP, "pt_create: no HIP device (%s); this library has no CPU fallback", hipGetErrorString(e));
+	if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PT_EINVAL, "pt_create: device %d of %d", cfg->device, ndev);
+
+	pt_ctx *c = new pt_ctx();
+	c->cfg = *cfg;
+	c->cfg.world = world;
+#define CREATE_TRY(call)                                                                              \
+	do {                                                                                              \
+		hipError_t e_ = (call);                                                                       \
+		if (e_ != hipSuccess) {                                                                       \
+			fail(nullptr, PT_EHIP, "%s: %s", #call, hipGetErrorString(e_));                          \
+			pt_destroy(c);                                                                            \
+			return PT_EHIP;                                                                           \
+		}                                                                                             \
+	} while (0)
+	CREATE_TRY(hipSetDevice(cfg->device));
+	hipDeviceProp_t prop;
+	CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+	c->n_cu = prop.multiProcessorCount;
+	CREATE_TRY(hipStreamCreate(&c->stream));
+
+	int blocks_per_cu = 0;
+	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false>, PT_TRACE_BLOCK, 0));
+	if (blocks_per_cu < 1) blocks_per_cu = 1;
+	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	c->trace_grid = c->n_cu * blocks_per_cu;
+
+	c->n_paths = own_tiles(cfg->width, cfg->height, cfg->partition, cfg->rank, world) * 64u;
+	c->stride = (c->n_paths + 255u) & ~255u;
+	if (c->stride == 0) c->stride = 256;
+	const size_t qbytes = (size_t) kQueueCols * c->stride * 4;
+	CREATE_TRY(hipMalloc(&c->queue_alloc, 2 * qbytes));
+	CREATE_TRY(hipMemsetAsync(c->queue_alloc, 0, 2 * qbytes, c->stream));
+	char *p = (char *) c->queue_alloc;
+	carve_queue(c->q[0], p, c->stride);
+	carve_queue(c->q[1], p, c->stride);
+	CREATE_TRY(hipMalloc((void **) &c->ctl, sizeof(DevCtl)));
+	CREATE_TRY(hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
+	CREATE_TRY(hipMalloc((void **) &c->spill, (size_t) c->trace_grid * PT_TRACE_WAVES * PT_SPILL_STACK * 64 * 4));
+	const size_t fb_bytes = (size_t) cfg->width * cfg->height * 16;
+	CREATE_TRY(hipMalloc((void **) &c->fb, fb_bytes));
+	CREATE_TRY(hipMemsetAsync(c->fb, 0, fb_bytes, c->stream));
+	CREATE_TRY(hipStreamSynchronize(c->stream));
+#undef CREATE_TRY
+	*out = c;
+	return PT_OK;
+}
+
+int pt_destroy(pt_ctx *c)
+{
+	if (!c) return PT_OK;
+	hipSetDevice(c->cfg.device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	for (EventPair &ev : c->pending) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	for (EventPair &ev : c->free_events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	free_scene(c);
+	if (c->queue_alloc) hipFree(c->queue_alloc);
+	if (c->ctl) hipFree(c->ctl);
+	if (c->spill) hipFree(c->spill);
+	if (c->fb) hipFree(c->fb);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+	return PT_OK;
+}
+
+int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
+{
+	if (!c || !s) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	if (!s->tris || s->n_tris == 0 || !s->nodes || s->n_nodes == 0 || !s->materials || s->n_materials == 0)
+		return fail(c, PT_EINVAL, "pt_upload_scene: triangles, nodes and materials must be non-empty");
+	if (s->n_nodes > (1u << 24) || s->n_tris > (1u << 24))
+		return fail(c, PT_EINVAL, "pt_upload_scene: node/triangle indices are stored as floats and stop being exact above 2^24");
+	if ((s->n_spheres && !s->spheres) || (s->n_light_tris && !s->light_tris) || (s->n_light_spheres && !s->light_spheres))
+		return fail(c, PT_EINVAL, "pt_upload_scene: null array with non-zero count");
+	if ((s->n_nodes & 1u) == 0) return fail(c, PT_EINVAL, "pt_upload_scene: a sibling-pair BVH has an odd node count (got %u)", s->n_nodes);
+	// host-side shape checks so that no kernel can index out of bounds
+	{
+		const float *nd = (const float *) s->nodes;
+		for (uint32_t i = 0; i < s->n_nodes; i++) {
+			const float first = nd[8 * i + 3], count = nd[8 * i + 7];
+			if (!(first >= 0.0f) || !(count >= 0.0f)) return fail(c, PT_EINVAL, "pt_upload_scene: node %u has a negative/NaN index", i);
+			if (count > 0.0f) {
+				if ((uint64_t) first + (uint64_t) count > s->n_tris) return fail(c, PT_EINVAL, "pt_upload_scene: leaf %u runs past the triangle array", i);
+			} else if (i + 0 < s->n_nodes && s->n_nodes > 1) {
+				if ((uint64_t) first + 1 >= s->n_nodes || (uint32_t) first == 0) return fail(c, PT_EINVAL, "pt_upload_scene: node %u has child index %g outside the array", i, (double) first);
+			}
+		}
+		const uint32_t *tr = (const uint32_t *) s->tris;
+		for (uint32_t i = 0; i < s->n_tris; i++)
+			if (tr[16 * i + 15] >= s->n_materials) return fail(c, PT_EINVAL, "pt_upload_scene: triangle %u uses material %u of %u", i, tr[16 * i + 15], s->n_materials);
+		const uint32_t *sp = (const uint32_t *) s->spheres;
+		for (uint32_t i = 0; i < s->n_spheres; i++)
+			if (sp[8 * i + 4] >= s->n_materials) return fail(c, PT_EINVAL, "pt_upload_scene: sphere %u uses material %u of %u", i, sp[8 * i + 4], s->n_materials);
+		for (uint32_t i = 0; i < s->n_light_tris; i++)
+			if (s->light_tris[i] >= s->n_tris) return fail(c, PT_EINVAL, "pt_upload_scene: light triangle index out of range");
+		for (uint32_t i = 0; i < s->n_light_spheres; i++)
+			if (s->light_spheres[i] >= s->n_spheres) return fail(c, PT_EINVAL, "pt_upload_scene: light sphere index out of range");
+	}
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	free_scene(c);
+	DevScene d;
+	memset(&d, 0, sizeof d);
+	int rc;
+	// 32 bytes of front padding put node 1 (and with it every sibling pair) on a 64-byte boundary
+	char *nodes = nullptr;
+	if ((rc = upload(c, s->nodes, (size_t) s->n_nodes * 32, &nodes, 32 + 64))) return rc;
+	// hipMalloc is 256-B aligned; (32+64) keeps node 0 at offset 96, node 1 at 128
+	d.nodes = (const float4 *) nodes;
+	char *tmp = nullptr;
+	if ((rc = upload(c, s->tris, (size_t) s->n_tris * 64, &tmp))) return rc;
+	d.tris = (const float4 *) tmp;
+	if ((rc = upload(c, s->materials, (size_t) s->n_materials * 48, &tmp))) return rc;
+	d.mats = (const float4 *) tmp;
+	if ((rc = upload(c, s->spheres, (size_t) s->n_spheres * 32, &tmp))) return rc;
+	d.spheres = (const float4 *) tmp;
+	uint32_t *u = nullptr;
+	if ((rc = upload(c, s->light_tris, (size_t) s->n_light_tris * 4, &u))) return rc;
+	d.light_tris = u;
+	if ((rc = upload(c, s->light_spheres, (size_t) s->n_light_spheres * 4, &u))) return rc;
+	d.light_spheres = u;
+	uint8_t *b = nullptr;
+	if (s->env_rgb8 && s->env_w && s->env_h) {
+		if ((rc = upload(c, s->env_rgb8, (size_t) s->env_w * s->env_h * 3, &b))) return rc;
+		d.env = b; d.env_w = s->env_w; d.env_h = s->env_h;
+	}
+	if (s->tex_rgb8 && s->tex_layers) {
+		if ((rc = upload(c, s->tex_rgb8, (size_t) s->tex_layers * 512 * 512 * 3, &b))) return rc;
+		d.tex = b; d.tex_layers = s->tex_layers;
+	}
+	d.n_nodes = s->n_nodes; d.n_tris = s->n_tris; d.n_mats = s->n_materials; d.n_spheres = s->n_spheres;
+	d.n_light_tris = s->n_light_tris; d.n_light_spheres = s->n_light_spheres;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->sc = d;
+	c->have_scene = true;
+	return PT_OK;
+}
+
+int pt_set_camera(pt_ctx *c, const float cam[12])
+{
+	if (!c || !cam) return PT_EINVAL;
+	memcpy(c->cam, cam, sizeof c->cam);
+	c->have_camera = true;
+	return PT_OK;
+}
+
+int pt_render_frame(pt_ctx *c, const uint32_t frame_data[4])
+{
+	if (!c || !frame_data) return PT_EINVAL;
+	if (!c->have_scene || !c->have_camera) return fail(c, PT_ESTATE, "pt_render_frame: upload a scene and set the camera first");
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	if (c->n_paths == 0) { c->frames++; return PT_OK; }
+	if (c->pending.size() > 4096) { int rc = drain_events(c); if (rc) return rc; }
+
+	ShadeArgs sa;
+	memset(&sa, 0, sizeof sa);
+	sa.sc = c->sc;
+	sa.stride = c->stride;
+	sa.ctl = c->ctl;
+	memcpy(sa.cam, c->cam, sizeof sa.cam);
+	sa.width = c->cfg.width; sa.height = c->cfg.height;
+	sa.seed = frame_data[0]; sa.frame = frame_data[1]; sa.bounces = frame_data[2];
+	sa.flags = c->cfg.flags;
+	sa.fb = c->fb;
+	sa.rank = c->cfg.rank; sa.world = c->cfg.world; sa.partition = c->cfg.partition; sa.n_paths = c->n_paths;
+	const dim3 sgrid((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock(PT_SHADE_BLOCK);
+
+	sa.out = c->q[0];
+	begin_timed(c, 1);
+	hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, c->stream, sa);
+	end_timed(c);
+	uint32_t qi = 0;
+	for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
+		int rc = launch_trace(c, queue_trace_args(c, qi, stage > 0));
+		if (rc) return rc;
+		sa.in = c->q[qi]; sa.out = c->q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
+		begin_timed(c, 1);
+		hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, c->stream, sa);
+		end_timed(c);
+		qi ^= 1u;
+	}
+	HIP_TRY(c, hipGetLastError());
+	c->frames++;
+	return PT_OK;
+}
+
+int pt_render(pt_ctx *c, uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces)
+{
+	if (!c || (n_frames && !seeds)) return PT_EINVAL;
+	for (uint32_t f = 0; f < n_frames; f++) {
+		const uint32_t fd[4] = {seeds[f], first_frame + f, bounces, 0};
+		int rc = pt_render_frame(c, fd);
+		if (rc) return rc;
+	}
+	return PT_OK;
+}
+
+int pt_sync(pt_ctx *c)
+{
+	if (!c) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+int pt_read_framebuffer(pt_ctx *c, float *rgba, size_t n_floats)
+{
+	if (!c || !rgba) return PT_EINVAL;
+	const size_t need = (size_t) c->cfg.width * c->cfg.height * 4;
+	if (n_floats != need) return fail(c, PT_EINVAL, "pt_read_framebuffer: expected %zu floats, got %zu", need, n_floats);
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	HIP_TRY(c, hipMemcpyAsync(rgba, c->fb, need * 4, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	return PT_OK;
+}
+
+int pt_clear_framebuffer(pt_ctx *c)
+{
+	if (!c) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	HIP_TRY(c, hipMemsetAsync(c->fb, 0, (size_t) c->cfg.width * c->cfg.height * 16, c->stream));
+	return PT_OK;
+}
+
+int pt_framebuffer_device(pt_ctx *c, void **dev_ptr)
+{
+	if (!c || !dev_ptr) return PT_EINVAL;
+	*dev_ptr = c->fb;
+	return PT_OK;
+}
+
+int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *hit4_dev)
+{
+	if (!c || !ray6_dev || !hit4_dev) return PT_EINVAL;
+	if (!c->have_scene) return fail(c, PT_ESTATE, "pt_trace_closest: upload a scene first");
+	if (n == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	HIP_TRY(c, hipMemsetAsync(&c->ctl->work, 0, 4, c->stream));
+	TraceArgs ta;
+	memset(&ta, 0, sizeof ta);
+	ta.sc = c->sc;
+	ta.seg[0].ray = (const float *) ray6_dev; ta.seg[0].hit = (uint32_t *) hit4_dev;
+	ta.stride = n; ta.n_fixed = n; ta.n_segs = 1;
+	ta.refill_threshold = 24;
+	ta.ctl = c->ctl;
+	ta.spill = c->spill;
+	return launch_trace(c, ta);
+}
+
+int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv)
+{
+	if (!c || (n && (!ro || !rd || !prim || !t_h || !kind))) return PT_EINVAL;
+	if (!c->have_scene) return fail(c, PT_ESTATE, "pt_trace_closest: upload a scene first");
+	if (n == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	std::vector<float> soa((size_t) 6 * n);
+	for (uint32_t i = 0; i < n; i++)
+		for (int k = 0; k < 3; k++) { soa[(size_t) k * n + i] = ro[3 * (size_t) i + k]; soa[(size_t) (3 + k) * n + i] = rd[3 * (size_t) i + k]; }
+	float *d_ray = nullptr; uint32_t *d_hit = nullptr;
+	HIP_TRY(c, hipMalloc((void **) &d_ray, (size_t) 6 * n * 4));
+	hipError_t e = hipMalloc((void **) &d_hit, (size_t) 4 * n * 4);
+	if (e != hipSuccess) { hipFree(d_ray); return fail(c, PT_EHIP, "hipMalloc: %s", hipGetErrorString(e)); }
+	std::vector<uint32_t> hit((size_t) 4 * n);
+	int rc = PT_OK;
+	do {
+		if ((e = hipMemcpyAsync(d_ray, soa.data(), soa.size() * 4, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+		if ((rc = pt_trace_closest_device(c, d_ray, n, d_hit))) break;
+		if ((e = hipMemcpyAsync(hit.data(), d_hit, hit.size() * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+		e = hipStreamSynchronize(c->stream);
+	} while (0);
+	hipFree(d_ray); hipFree(d_hit);
+	if (rc) return rc;
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_trace_closest: %s", hipGetErrorString(e));
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t tk = hit[(size_t) n + i];
+		kind[i] = (uint8_t) (tk >> 16);
+		prim[i] = kind[i] ? hit[i] : 0xffffffffu;
+		t_h[i] = kind[i] ? (uint16_t) (tk & 0xffffu) : 0;
+		if (uv) {
+			memcpy(&uv[2 * (size_t) i], &hit[(size_t) 2 * n + i], 4);
+			memcpy(&uv[2 * (size_t) i + 1], &hit[(size_t) 3 * n + i], 4);
+			if (kind[i] != 1) uv[2 * (size_t) i] = uv[2 * (size_t) i + 1] = 0.0f;
+		}
+	}
+	return PT_OK;
+}
+
+int pt_get_counters(pt_ctx *c, pt_counters *out)
+{
+	if (!c || !out) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	int rc = drain_events(c);
+	if (rc) return rc;
+	DevCtl h;
+	HIP_TRY(c, hipMemcpyAsync(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	memset(out, 0, sizeof *out);
+	out->frames = c->frames;
+	out->paths = h.paths; out->rays_primary = h.rays_primary; out->rays_shadow = h.rays_shadow; out->rays_bounce = h.rays_bounce;
+	out->node_steps = h.node_steps; out->tri_tests = h.tri_tests; out->stack_spills = h.stack_spills;
+	out->ms_trace = c->ms_trace; out->ms_shade = c->ms_shade; out->trace_launches = c->trace_launches;
+	return PT_OK;
+}
+
+int pt_reset_counters(pt_ctx *c)
+{
+	if (!c) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	int rc = drain_events(c);
+	if (rc) return rc;
+	HIP_TRY(c, hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->ms_trace = c->ms_shade = 0; c->trace_launches = 0; c->frames = 0;
+	return PT_OK;
+}
+
+uint32_t pt_partition_count(uint32_t width, uint32_t height, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	if (world == 0) world = 1;
+	if ((width & 7u) || (height & 7u) || rank >= world) return 0;
+	return own_tiles(width, height, partition, rank, world) * 64u;
+}
+
+int pt_partition_pixels(uint32_t width, uint32_t height, uint32_t partition, uint32_t rank, uint32_t world, uint32_t *pixels)
+{
+	if (world == 0) world = 1;
+	if (!pixels || (width & 7u) || (height & 7u) || rank >= world) return PT_EINVAL;
+	const uint32_t n = own_tiles(width, height, partition, rank, world) * 64u;
+	for (uint32_t p = 0; p < n; p++) pixels[p] = host_path_pixel(p, width, partition, rank, world);
+	return PT_OK;
+}
+
+int pt_pack_owned(pt_ctx *c, void *dst_dev)
+{
+	if (!c || !dst_dev) return PT_EINVAL;
+	if (c->n_paths == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	hipLaunchKernelGGL(k_pack_owned, dim3((c->n_paths + 255) / 256), dim3(256), 0, c->stream, (const float4 *) c->fb, (float4 *) dst_dev,
+	                   c->n_paths, c->cfg.width, c->cfg.partition, c->cfg.rank, c->cfg.world);
+	HIP_TRY(c, hipGetLastError());
+	return PT_OK;
+}
+
+int pt_unpack_from(pt_ctx *c, const void *src_dev, uint32_t from_rank, uint32_t world)
+{
+	if (!c || !src_dev) return PT_EINVAL;
+	if (world == 0) world = 1;
+	if (from_rank >= world) return fail(c, PT_EINVAL, "pt_unpack_from: rank %u outside world %u", from_rank, world);
+	const uint32_t n = own_tiles(c->cfg.width, c->cfg.height, PT_PARTITION_TILES, from_rank, world) * 64u;
+	if (n == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	hipLaunchKernelGGL(k_unpack_from, dim3((n + 255) / 256), dim3(256), 0, c->stream, (float4 *) c->fb, (const float4 *) src_dev, n,
+	                   c->cfg.width, (uint32_t) PT_PARTITION_TILES, from_rank, world);
+	HIP_TRY(c, hipGetLastError());
+	return PT_OK;
+}
+
+int pt_debug_read_queue(pt_ctx *c, uint32_t queue, uint32_t field, void *out, size_t n_words, uint32_t *stride, uint32_t *count)
+{
+	if (!c || queue > 1 || field > 10 || !out) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	const PathQ &q = c->q[queue];
+	const void *base[11] = {q.pix, q.rng, q.meta, q.thr, q.col, q.ray, q.sray, q.nee, q.bs, q.hit, q.shit};
+	const uint32_t cols[11] = {1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4};
+	const size_t need = (size_t) cols[field] * c->stride;
+	if (n_words != need) return fail(c, PT_EINVAL, "pt_debug_read_queue: field %u needs %zu words", field, need);
+	HIP_TRY(c, hipMemcpyAsync(out, base[field], need * 4, hipMemcpyDeviceToHost, c->stream));
+	uint32_t qc[2];
+	HIP_TRY(c, hipMemcpyAsync(qc, c->ctl->qcount, 8, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (stride) *stride = c->stride;
+	if (count) *count = qc[queue];
+	return PT_OK;
+}
+
+int pt_debug_eval(pt_ctx *c, int op, const float *a, const float *b, uint32_t n, float *out)
+{
+	if (!c || !a || !out) return PT_EINVAL;
+	if (n == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	float *da = nullptr, *db = nullptr, *dout = nullptr;
+	HIP_TRY(c, hipMalloc((void **) &da, (size_t) n * 4));
+	HIP_TRY(c, hipMalloc((void **) &dout, (size_t) n * 4));
+	if (b) HIP_TRY(c, hipMalloc((void **) &db, (size_t) n * 4));
+	hipMemcpyAsync(da, a, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
+	if (b) hipMemcpyAsync(db, b, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
+	hipLaunchKernelGGL(k_debug_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, (const float *) da, (const float *) db, n, dout);
+	hipMemcpyAsync(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream);
+	hipError_t e = hipStreamSynchronize(c->stream);
+	hipFree(da); hipFree(dout); if (db) hipFree(db);
+	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_debug_eval: %s", hipGetErrorString(e));
+	return PT_OK;
+}
+
+} // extern "C"
