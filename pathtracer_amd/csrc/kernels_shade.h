@@ -309,10 +309,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
 	if (p == 0) {
 		a.ctl->qcount[0] = a.n_paths;
 		a.ctl->qcount[1] = 0;
-		a.ctl->work = 0;
 		atomicAdd(&a.ctl->paths, (unsigned long long) a.n_paths);
 		atomicAdd(&a.ctl->rays_primary, (unsigned long long) a.n_paths);
 	}
+	if (p < PT_SHARDS) a.ctl->shard[p * PT_SHARD_STRIDE] = 0;
 	if (p >= a.n_paths) return;
 	const uint32_t pixel = path_pixel(p, a.width, a.partition, a.rank, a.world);
 	const uint32_t px = pixel % a.width, py = pixel / a.width;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n_in = a.ctl->qcount[a.in_q];
-	if (i == 0) a.ctl->work = 0;
+	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
 	bool alive = i < n_in;

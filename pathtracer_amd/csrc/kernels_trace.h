@@ -17,6 +17,12 @@
 #define PT_SPILL_STACK 48   // 16 + 48 = 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_BLOCK 256
 #define PT_TRACE_WAVES (PT_TRACE_BLOCK / 64)
+// Work distribution: the ray range is cut into 64-ray units; the units are dealt to PT_SHARDS contiguous shards,
+// each with its own counter on its own 128-byte line.  A wave pulls one unit at a time from its home shard and
+// walks on to the next shard when one runs dry, so no single word sees more than total/(64*PT_SHARDS) atomics
+// (one word saturates at ~88 atomics/us on this chip; a single counter made the first version atomic-bound).
+#define PT_SHARDS 64
+#define PT_SHARD_STRIDE 32
 
 struct DevScene {
 	const float4 *nodes;   // node i at nodes[2*i]; allocation is shifted so pairs (2k+1, 2k+2) are 64-B aligned
@@ -33,9 +39,10 @@ struct DevScene {
 // device control block shared by the kernels of one context
 struct DevCtl {
 	uint32_t qcount[2];   // live entries of the two path queues
-	uint32_t work;        // trace work counter
+	uint32_t work;        // unused (kept for layout)
 	uint32_t pad;
 	unsigned long long rays_primary, rays_shadow, rays_bounce, node_steps, tri_tests, stack_spills, paths, pad2;
+	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE]; // trace work counters, zeroed by the kernel before each trace launch
 };
 
 // One segment of rays: structure-of-arrays with a common stride.
@@ -119,20 +126,43 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 	float best_u = 0.0f, best_v = 0.0f;
 	uint32_t n_steps = 0, n_tests = 0, n_spills = 0;
 	bool exhausted = (total == 0);
+	// wave-uniform work state
+	uint32_t loc_next = 0, loc_end = 0; // the unit this wave is handing out to its lanes
+	const uint32_t total_units = (total + 63u) >> 6;
+	const uint32_t units_per_shard = (total_units + PT_SHARDS - 1u) / PT_SHARDS;
+	uint32_t shard = (blockIdx.x * PT_TRACE_WAVES + wave) % PT_SHARDS, shards_done = 0;
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill idle lanes
 		const unsigned long long idle = __ballot(!active);
 		const uint32_t n_idle = (uint32_t) __popcll(idle);
 		if (!exhausted && n_idle > 0u && (n_idle == 64u || n_idle >= a.refill_threshold)) {
-			uint32_t base = 0;
-			if (lane == (uint32_t) __builtin_ctzll(idle)) base = atomicAdd(&a.ctl->work, n_idle);
-			base = __shfl(base, __builtin_ctzll(idle));
-			if (base + n_idle >= total) exhausted = true;
+			if (loc_next == loc_end) {
+				bool found = false;
+				while (shards_done < PT_SHARDS) {
+					uint32_t u = 0;
+					if (lane == 0) u = atomicAdd(&a.ctl->shard[shard * PT_SHARD_STRIDE], 1u);
+					u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+					const uint32_t unit = shard * units_per_shard + u;
+					if (u < units_per_shard && unit < total_units) {
+						loc_next = unit << 6;
+						loc_end = loc_next + 64u < total ? loc_next + 64u : total;
+						found = true;
+						break;
+					}
+					shard = shard + 1u == PT_SHARDS ? 0u : shard + 1u; // this shard is dry for good: never revisited
+					shards_done++;
+				}
+				if (!found) exhausted = true;
+			}
+			const uint32_t avail = loc_end - loc_next;
+			const uint32_t take = n_idle < avail ? n_idle : avail;
+			const uint32_t base = loc_next;
+			loc_next += take;
 			if (!active) {
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
 				const uint32_t w = base + rank;
-				if (w < total) {
+				if (rank < take) {
 					seg = w >= n_per_seg ? 1u : 0u;
 					slot = w - seg * n_per_seg;
 					const RaySeg &rs = a.seg[seg];

@@ -26,6 +26,7 @@ struct pt_ctx {
 	std::string err;
 	int n_cu = 0;
 	int trace_grid = 0;
+	uint32_t refill_threshold = 24;
 
 	// scene
 	DevScene sc{};
@@ -164,7 +165,7 @@ TraceArgs queue_trace_args(pt_ctx *c, uint32_t qi, bool with_shadow)
 	ta.stride = c->stride;
 	ta.count_ptr = &c->ctl->qcount[qi];
 	ta.n_segs = with_shadow ? 2 : 1;
-	ta.refill_threshold = 24;
+	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = c->ctl;
 	ta.zero_on_entry = &c->ctl->qcount[qi ^ 1u];
 	ta.spill = c->spill;
@@ -218,6 +219,9 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false>, PT_TRACE_BLOCK, 0));
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
+	// tuning knobs (defaults are the measured optimum)
+	if (const char *e = getenv("PT355_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= blocks_per_cu) blocks_per_cu = v; }
+	if (const char *e = getenv("PT355_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t) v; }
 	c->trace_grid = c->n_cu * blocks_per_cu;
 
 	c->n_paths = own_tiles(cfg->width, cfg->height, cfg->partition, cfg->rank, world) * 64u;
@@ -430,13 +434,13 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	if (!c->have_scene) return fail(c, PT_ESTATE, "pt_trace_closest: upload a scene first");
 	if (n == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	HIP_TRY(c, hipMemsetAsync(&c->ctl->work, 0, 4, c->stream));
+	HIP_TRY(c, hipMemsetAsync(c->ctl->shard, 0, sizeof(c->ctl->shard), c->stream));
 	TraceArgs ta;
 	memset(&ta, 0, sizeof ta);
 	ta.sc = c->sc;
 	ta.seg[0].ray = (const float *) ray6_dev; ta.seg[0].hit = (uint32_t *) hit4_dev;
 	ta.stride = n; ta.n_fixed = n; ta.n_segs = 1;
-	ta.refill_threshold = 24;
+	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = c->ctl;
 	ta.spill = c->spill;
 	return launch_trace(c, ta);
