@@ -24,3 +24,17 @@ def ol():
     import oracle_lib
     oracle_lib.load()
     return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = dict(np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=False))
+        return cache[name]
+
+    return load
