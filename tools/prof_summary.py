@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by tools/prof.sh into one per-kernel table (mean per dispatch)."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    name = name.split("(")[0]
+    for k in ("k_trace", "k_shade", "k_raygen", "k_pack", "k_unpack"):
+        if k in name:
+            return k + ("<count>" if "Lb1" in name or "<true>" in name else "")
+    return name[:40]
+
+
+print("== kernel-trace stats (rocprofv3 --kernel-trace --stats)")
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        print(f"{short(row['Name']):24s} calls {row['Calls']:>6s}  avg {float(row['AverageNs'])/1e3:9.1f} us  total {float(row['TotalDurationNs'])/1e6:9.2f} ms  {row['Percentage']}%")
+
+acc = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(lambda: defaultdict(int))
+for f in glob.glob(os.path.join(out, "*", "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        acc[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        cnt[k][row["Counter_Name"]] += 1
+print("\n== PMC, mean per dispatch")
+for k in sorted(acc):
+    print(f"[{k}]")
+    m = {c: acc[k][c] / max(cnt[k][c], 1) for c in acc[k]}
+    for c in sorted(m):
+        print(f"   {c:36s} {m[c]:16.1f}   (n={cnt[k][c]})")
+    g = m.get
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+        print(f"   -> VALU lane utilisation   {g('SQ_THREAD_CYCLES_VALU') / (g('SQ_ACTIVE_INST_VALU') * 64) * 100:6.1f} %  (THREAD_CYCLES_VALU / (ACTIVE_INST_VALU*64))")
+    if g("SQ_WAVE_CYCLES"):
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VMEM"):
+            if g(c) is not None:
+                print(f"   -> {c:24s} / SQ_WAVE_CYCLES = {g(c) / g('SQ_WAVE_CYCLES') * 100:6.1f} %")
+    if g("SQ_BUSY_CYCLES") and g("SQ_WAVE_CYCLES"):
+        print(f"   -> mean waves in flight per SQ-busy cycle = {g('SQ_WAVE_CYCLES') / g('SQ_BUSY_CYCLES'):6.2f}")
+    if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None and g("TCC_HIT_sum") + g("TCC_MISS_sum") > 0:
+        print(f"   -> L2 hit rate {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')) * 100:6.1f} %")
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+        print(f"   -> L1 (TCP) miss share {g('TCP_TCC_READ_REQ_sum') / g('TCP_TOTAL_CACHE_ACCESSES_sum') * 100:6.1f} %  (TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)")
+    if g("FETCH_SIZE") is not None or g("WRITE_SIZE") is not None:
+        f_, w_ = g("FETCH_SIZE") or 0.0, g("WRITE_SIZE") or 0.0
+        print(f"   -> HBM-side traffic per dispatch: 2*FETCH_SIZE {2 * f_ * 1024 / 1e6:9.3f} MB + WRITE_SIZE {w_ * 1024 / 1e6:9.3f} MB  (gfx950: FETCH_SIZE counts 64 B per 128-B request)")
