@@ -52,7 +52,9 @@ typedef struct pt_config {
 	uint32_t flags;
 	uint32_t partition;    /* PT_PARTITION_* */
 	uint32_t rank, world;  /* this context's share; world = 0 or 1 means the whole image */
-	uint32_t reserved[9];
+	uint32_t max_batch;    /* frames pt_render traces together (1..16); 0 = default (8, less for very large images).
+	                          Results do not depend on it: samples are blended into the image in frame order. */
+	uint32_t reserved[8];
 } pt_config;
 
 /* Replaces: the six PushDataToSSBO calls, bindings 0..5 in call order (src/main.cpp:57-63,
@@ -101,7 +103,8 @@ int pt_set_camera(pt_ctx *ctx, const float cam[12]);
  * stream; pt_sync or any read-back orders it. */
 int pt_render_frame(pt_ctx *ctx, const uint32_t frame_data[4]);
 
-/* n_frames consecutive pt_render_frame calls: frame numbers first_frame.., seeds[i] per frame. */
+/* Same result as n_frames consecutive pt_render_frame calls (frame numbers first_frame.., seeds[i] per frame), but up
+ * to pt_config.max_batch frames share one set of kernel launches; their samples are blended in frame order. */
 int pt_render(pt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces);
 
 int pt_sync(pt_ctx *ctx);
@@ -118,8 +121,8 @@ int pt_framebuffer_device(pt_ctx *ctx, void **dev_ptr);
  * prim: full 32-bit primitive index; t_h: fp16 bits of HitData.t; uv: optional, 2 floats per ray. */
 int pt_trace_closest(pt_ctx *ctx, const float *ro, const float *rd, uint32_t n,
                      uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv);
-/* Same kernel on rays already resident in HBM, structure-of-arrays: ray6 = ro.x[n] ro.y[n] ro.z[n]
- * rd.x[n] rd.y[n] rd.z[n]; hit4 = prim[n] (u32) tk[n] (t_h | kind<<16) u[n] v[n].  Asynchronous. */
+/* Same kernel on rays already resident in HBM: ray6 = structure-of-arrays ro.x[n] ro.y[n] ro.z[n] rd.x[n] rd.y[n]
+ * rd.z[n]; hit4 = one 16-byte record per ray, 16-byte aligned: {prim u32, t_h | kind<<16, u f32, v f32}.  Asynchronous. */
 int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
 
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);

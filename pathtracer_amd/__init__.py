@@ -29,7 +29,7 @@ class PtError(RuntimeError):
 
 class pt_config(ctypes.Structure):
     _fields_ = [("width", c_uint32), ("height", c_uint32), ("device", c_int32), ("flags", c_uint32),
-                ("partition", c_uint32), ("rank", c_uint32), ("world", c_uint32), ("reserved", c_uint32 * 9)]
+                ("partition", c_uint32), ("rank", c_uint32), ("world", c_uint32), ("max_batch", c_uint32), ("reserved", c_uint32 * 8)]
 
 
 class pt_scene_desc(ctypes.Structure):
@@ -231,9 +231,10 @@ class PathTracer:
     """One pt_ctx: the replacement for the reference's GL upload + glDispatchCompute sequence."""
 
     def __init__(self, width: int, height: int, device: int = 0, flags: int = 0, partition: int = PT_PARTITION_FULL,
-                 rank: int = 0, world: int = 1):
+                 rank: int = 0, world: int = 1, max_batch: int = 0):
         L = lib()
-        cfg = pt_config(width=width, height=height, device=device, flags=flags, partition=partition, rank=rank, world=world)
+        cfg = pt_config(width=width, height=height, device=device, flags=flags, partition=partition, rank=rank, world=world,
+                        max_batch=max_batch)
         h = c_void_p()
         rc = L.pt_create(byref(cfg), byref(h))
         if rc != 0:
@@ -241,6 +242,7 @@ class PathTracer:
         self._h = h
         self.width, self.height = width, height
         self.rank, self.world, self.partition = rank, world, partition
+        self.max_batch = min(max_batch if max_batch else 8, 16)
         self._scene = None
 
     def _check(self, rc, what):
@@ -328,8 +330,9 @@ class PathTracer:
 
     def debug_read_queue(self, queue: int, field: int) -> np.ndarray:
         cols = [1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4][field]
-        stride = ((lib().pt_partition_count(self.width, self.height, self.partition, self.rank, self.world) + 255) // 256) * 256
-        out = np.zeros((cols, max(stride, 256)), np.uint32)
+        n_blocks = (self.max_batch * lib().pt_partition_count(self.width, self.height, self.partition, self.rank, self.world) + 255) // 256
+        stride = max((n_blocks + 63) // 64, 1) * 256 * 64  # 64 regions of whole shading blocks (csrc/kernels_trace.h)
+        out = np.zeros((cols, stride), np.uint32)
         st, cnt = c_uint32(), c_uint32()
         self._check(lib().pt_debug_read_queue(self._h, queue, field, _ptr(out), out.size, byref(st), byref(cnt)), "pt_debug_read_queue")
         return out, cnt.value

@@ -3,17 +3,20 @@
 //
 // A path lives in exactly one slot of the current queue; every per-path quantity is a structure-of-
 // arrays column indexed by that slot, so all queue traffic is coalesced.  A shading launch reads queue
-// `in`, and lanes whose path continues claim a slot of queue `out` with one atomic per wave
-// (ballot + mbcnt prefix).  Paths that end blend straight into the RGBA32F image: a pixel carries at
-// most one path per frame, so no atomics are needed there.
+// `in`; lanes whose path continues are compacted into queue `out`: ballot + mbcnt prefix inside a wave,
+// the four wave counts summed through LDS, ONE returning atomic per 256-thread block on the fill counter
+// of the block's output region (block b fills region b % PT_SHARDS; see kernels_trace.h).  Paths that
+// end blend straight into the RGBA32F image: a pixel carries at most one path per frame, so no atomics
+// are needed there.
 #pragma once
 #include "kernels_trace.h"
 
 #define PT_SHADE_BLOCK 256
+#define PT_MAX_BATCH 16   // frames (samples per pixel) traced together by one set of launches
 
 // columns of one path queue; every array has `stride` entries per component
 struct PathQ {
-	uint32_t *pix;   // pixel index y*W+x
+	uint32_t *pix;   // path id in the batch: frame_slot * n_paths_frame + path-in-frame (k_raygen order)
 	uint32_t *rng;   // PCG state
 	uint32_t *meta;  // bit0: shadow ray present, bit1: can_use_NEE at x, bit2: material at x is SPECULAR_METAL
 	float *thr;      // 3: throughput_term
@@ -22,24 +25,30 @@ struct PathQ {
 	float *sray;     // 6: shadow ray origin x, direction                         (trace segment 1)
 	float *nee;      // 8: P = Le*BRDF*cos_x (3), A = pdf_light_area*d^2, pdf_BSDF(nee), y_nee (3)
 	float *bs;       // 5: BRDF (3), cos_theta_x, pdf_BSDF_sa of the sampled direction
-	uint32_t *hit;   // 4: closest hit of the bounce ray  (prim, t_h|kind<<16, u, v)
-	uint32_t *shit;  // 4: closest hit of the shadow ray
+	uint4 *hit;      // closest hit of the bounce ray, one 16-byte record: (prim, t_h|kind<<16, u, v)
+	uint4 *shit;     // closest hit of the shadow ray
 };
 
 struct ShadeArgs {
 	DevScene sc;
 	PathQ in, out;
 	uint32_t stride;
+	uint32_t cap;           // slots per queue region = blocks_per_region * PT_SHADE_BLOCK
+	uint32_t blocks_per_region;
 	DevCtl *ctl;
 	uint32_t in_q;          // index of `in` in ctl->qcount
 	float cam[12];
 	uint32_t width, height;
-	uint32_t seed, frame, bounces;
+	uint32_t bounces;
 	uint32_t stage;         // 0: after the primary trace; k: after the trace of bounce k
 	uint32_t flags;
+	float4 *sample;         // [n_batch][n_paths_frame]: the finished sample of every path of the batch
 	float *fb;
-	// partition (raygen only)
-	uint32_t rank, world, partition, n_paths;
+	// batch: n_batch consecutive frames first_frame.. with their host-PCG seeds (FrameData.x), traced together
+	uint32_t n_batch, first_frame, n_paths_frame, per_region;
+	uint32_t seeds[PT_MAX_BATCH];
+	// partition (raygen / resolve only)
+	uint32_t rank, world, partition;
 };
 
 struct HitRec { // HitData, fc:214-222, members widened to float where they are float16_t
@@ -302,21 +311,26 @@ PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint3
 	return y * width + x;
 }
 
-// main() + render_function(), fc:1088-1122: seed, pixel jitter, pinhole ray.
+// main() + render_function(), fc:1088-1122: seed, pixel jitter, pinhole ray -- for every pixel this rank owns, for
+// every frame of the batch.  Path p (frame slot p / n_paths_frame) starts in region p / per_region of queue 0.
 __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
 {
 	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t n_total = a.n_batch * a.n_paths_frame;
 	if (p == 0) {
-		a.ctl->qcount[0] = a.n_paths;
-		a.ctl->qcount[1] = 0;
-		atomicAdd(&a.ctl->paths, (unsigned long long) a.n_paths);
-		atomicAdd(&a.ctl->rays_primary, (unsigned long long) a.n_paths);
+		atomicAdd(&a.ctl->paths, (unsigned long long) n_total);
+		atomicAdd(&a.ctl->rays_primary, (unsigned long long) n_total);
 	}
-	if (p < PT_SHARDS) a.ctl->shard[p * PT_SHARD_STRIDE] = 0;
-	if (p >= a.n_paths) return;
-	const uint32_t pixel = path_pixel(p, a.width, a.partition, a.rank, a.world);
+	if (p < PT_SHARDS) {
+		const uint32_t lo = p * a.per_region;
+		a.ctl->qcount[0][p * PT_SHARD_STRIDE] = n_total > lo ? (n_total - lo < a.per_region ? n_total - lo : a.per_region) : 0u;
+		a.ctl->shard[p * PT_SHARD_STRIDE] = 0;
+	}
+	if (p >= n_total) return;
+	const uint32_t fslot = p / a.n_paths_frame;
+	const uint32_t pixel = path_pixel(p - fslot * a.n_paths_frame, a.width, a.partition, a.rank, a.world);
 	const uint32_t px = pixel % a.width, py = pixel / a.width;
-	uint32_t rng = seed3(px, py, a.seed);
+	uint32_t rng = seed3(px, py, a.seeds[fslot]);
 
 	const v3 cam_origin = V(a.cam[0], a.cam[1], a.cam[2]);
 	const v3 cam_forward = V(a.cam[4], a.cam[5], a.cam[6]);
@@ -337,41 +351,57 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
 	const v3 rd = normalize(point_on_grid - cam_origin);
 
 	const uint32_t st = a.stride;
-	a.out.pix[p] = pixel;
-	a.out.rng[p] = rng;
-	a.out.meta[p] = 0;
-	st3(a.out.thr, p, st, V(1.0f, 1.0f, 1.0f));
-	st3(a.out.col, p, st, V(0.0f, 0.0f, 0.0f));
-	st3(a.out.ray, p, st, cam_origin);
-	st3(a.out.ray + 3 * (size_t) st, p, st, rd);
+	const uint32_t region = p / a.per_region;
+	const uint32_t o = region * a.cap + (p - region * a.per_region);
+	a.out.pix[o] = p;
+	a.out.rng[o] = rng;
+	a.out.meta[o] = 0;
+	st3(a.out.thr, o, st, V(1.0f, 1.0f, 1.0f));
+	st3(a.out.col, o, st, V(0.0f, 0.0f, 0.0f));
+	st3(a.out.ray, o, st, cam_origin);
+	st3(a.out.ray + 3 * (size_t) st, o, st, rd);
 }
 
-// fc:1124-1129
-PT_DEV void accumulate(const ShadeArgs &a, uint32_t pixel, v3 color)
+// A finished path parks its sample; k_resolve blends the batch into the image in frame order.  (Several frames of
+// one pixel are in flight at once, and the running mean of fc:1124-1129 is order-dependent in floating point.)
+PT_DEV void accumulate(const ShadeArgs &a, uint32_t pid, v3 color)
 {
-	float4 *px = (float4 *) a.fb + pixel;
-	const float4 last = *px;
-	const float fa = (float) a.frame / (float) (a.frame + 1u), fb = 1.0f / (float) (a.frame + 1u);
-	float4 o;
-	o.x = fa * last.x + fb * color.x;
-	o.y = fa * last.y + fb * color.y;
-	o.z = fa * last.z + fb * color.z;
-	o.w = 1.0f;
-	*px = o;
+	a.sample[pid] = make_float4(color.x, color.y, color.z, 1.0f);
+}
+
+// fc:1124-1129, once per frame of the batch, in frame order: new = n/(n+1) * old + 1/(n+1) * sample, alpha = 1
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_resolve(ShadeArgs a)
+{
+	const uint32_t pf = blockIdx.x * blockDim.x + threadIdx.x;
+	if (pf >= a.n_paths_frame) return;
+	float4 *px = (float4 *) a.fb + path_pixel(pf, a.width, a.partition, a.rank, a.world);
+	float4 acc = *px;
+	for (uint32_t s = 0; s < a.n_batch; s++) {
+		const float4 c = a.sample[(size_t) s * a.n_paths_frame + pf];
+		const uint32_t frame = a.first_frame + s;
+		const float fa = (float) frame / (float) (frame + 1u), fb = 1.0f / (float) (frame + 1u);
+		acc.x = fa * acc.x + fb * c.x;
+		acc.y = fa * acc.y + fb * c.y;
+		acc.z = fa * acc.z + fb * c.z;
+		acc.w = 1.0f;
+	}
+	*px = acc;
 }
 
 // One shading stage.  stage 0 consumes the primary hit (fc:880-896); stage k >= 1 consumes the shadow and
 // bounce hits of bounce k (fc:970-1077) and, unless k == bounces, emits bounce k+1 (fc:901-968, 1009-1017).
 __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 {
+	__shared__ uint32_t s_live[PT_SHADE_BLOCK / 64], s_nee[PT_SHADE_BLOCK / 64], s_base;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t n_in = a.ctl->qcount[a.in_q];
+	const uint32_t in_region = blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size
+	const uint32_t n_in = a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
 	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
-	bool alive = i < n_in;
+	bool alive = i - in_region * a.cap < n_in;
 
-	uint32_t pixel = 0, rng = 0, meta = 0;
+	uint32_t pixel = 0 /* path id in the batch */, rng = 0, meta = 0;
 	v3 thr = V(0, 0, 0), col = V(0, 0, 0), ro = V(0, 0, 0), rd = V(0, 0, 0);
 	HitRec data;
 	data.t = 0; data.n = V(0, 0, 0); data.mat = 0; data.obj16 = 0; data.type = 0; data.uvx = 0; data.uvy = 0;
@@ -384,8 +414,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 		pixel = a.in.pix[i]; rng = a.in.rng[i]; meta = a.in.meta[i];
 		thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
 		ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
-		const uint32_t hp = a.in.hit[i], htk = a.in.hit[st + i];
-		const float hu = __uint_as_float(a.in.hit[2 * st + i]), hv = __uint_as_float(a.in.hit[3 * st + i]);
+		const uint4 hrec = a.in.hit[i];
+		const uint32_t hp = hrec.x, htk = hrec.y;
+		const float hu = __uint_as_float(hrec.z), hv = __uint_as_float(hrec.w);
 		const bool hit_anything = (htk >> 16) != 0u;
 
 		if (a.stage == 0) {
@@ -404,10 +435,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 			// ---- NEE of this bounce, resolved now that the shadow ray is back (fc:970-1006)
 			if (meta & 1u) {
 				v3 direct = V(0.0f, 0.0f, 0.0f);
-				const uint32_t sp_ = a.in.shit[i], stk = a.in.shit[st + i];
+				const uint4 srec = a.in.shit[i];
+				const uint32_t sp_ = srec.x, stk = srec.y;
 				if ((stk >> 16) != 0u) {
 					const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
-					const float su = __uint_as_float(a.in.shit[2 * st + i]), sv = __uint_as_float(a.in.shit[3 * st + i]);
+					const float su = __uint_as_float(srec.z), sv = __uint_as_float(srec.w);
 					const HitRec sh = hit_attributes(sc, sp_, stk, su, sv, sro, srd);
 					const v3 y_nee = ld3(a.in.nee + 5 * (size_t) st, i, st);
 					const v3 dlt = y_nee - (sro + srd * sh.t);
@@ -465,27 +497,44 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 		alive = false;
 	}
 
-	// ---- claim a slot of the next queue: one atomic per wave
+	// ---- claim slots of the next queue: one returning atomic per block, on the block's own output region
+	const uint32_t num_ls = num_light_sources;
+	bool can_use_nee = false;
+	if (alive) { // fc:914-915 for the vertex the next bounce leaves from (x = y, mat_x = mat_y)
+		const float a2 = mat_y.d1.w * mat_y.d1.w;
+		can_use_nee = num_ls > 0u && (mat_y.d2.w == 0.0f || mat_y.d2.w == 1.0f || (mat_y.d2.w == 2.0f && a2 > 0.0f));
+	}
 	const unsigned long long live = __ballot(alive);
-	if (live == 0ull) return;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t leader = (uint32_t) __builtin_ctzll(live);
-	uint32_t base = 0;
-	if (lane == leader) base = atomicAdd(&a.ctl->qcount[a.in_q ^ 1u], (uint32_t) __popcll(live));
-	base = __shfl(base, leader);
+	const unsigned long long sh_mask = __ballot(can_use_nee);
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (lane == 0) { s_live[wv] = (uint32_t) __popcll(live); s_nee[wv] = (uint32_t) __popcll(sh_mask); }
+	__syncthreads();
+	const uint32_t out_region = blockIdx.x % PT_SHARDS;
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0, nee = 0;
+		for (uint32_t w = 0; w < PT_SHADE_BLOCK / 64; w++) { tot += s_live[w]; nee += s_nee[w]; }
+		uint32_t base = 0;
+		if (tot) {
+			base = atomicAdd(&a.ctl->qcount[a.in_q ^ 1u][out_region * PT_SHARD_STRIDE], tot);
+			// rays are counted when they are enqueued
+			atomicAdd(&a.ctl->rays_bounce[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) tot);
+			if (nee) atomicAdd(&a.ctl->rays_shadow[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) nee);
+		}
+		s_base = base;
+	}
+	__syncthreads();
 	if (!alive) return;
-	const uint32_t o = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) live, 0u));
+	uint32_t o = out_region * a.cap + s_base;
+	for (uint32_t w = 0; w < wv; w++) o += s_live[w];
+	o += __builtin_amdgcn_mbcnt_hi((uint32_t) (live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) live, 0u));
 
 	// ---- emit bounce b = stage + 1 from x = y (fc:901-968, 1009-1017)
 	const v3 x = y;
 	const v3 normal_x = data.n;
 	const MatRec mat_x = mat_y;
-	const float alpha_squared = mat_x.d1.w * mat_x.d1.w;
 	const m3 tnb = tnb_rows(normal_x);
 	const m3 inverse_tnb = inverse(tnb);
 	const v3 wo = normalize(mul(tnb, -rd));
-	bool can_use_nee = num_light_sources > 0u;
-	can_use_nee = can_use_nee && (mat_x.d2.w == 0.0f || mat_x.d2.w == 1.0f || (mat_x.d2.w == 2.0f && alpha_squared > 0.0f));
 	uint32_t new_meta = (can_use_nee ? 3u : 0u) | (mat_x.d2.w == 2.0f ? 4u : 0u);
 	if (can_use_nee) {
 		const float pdf_pick_light = 1.0f / (float) num_light_sources;
@@ -576,13 +625,6 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 	st3(a.out.bs, o, st, brdf);
 	a.out.bs[3 * (size_t) st + o] = cos_theta_x;
 	a.out.bs[4 * (size_t) st + o] = pdf_bsdf_sa;
-
-	// rays are counted when they are enqueued
-	const unsigned long long sh_mask = __ballot(can_use_nee);
-	if (lane == leader) {
-		atomicAdd(&a.ctl->rays_bounce, (unsigned long long) __popcll(live));
-		if (sh_mask) atomicAdd(&a.ctl->rays_shadow, (unsigned long long) __popcll(sh_mask));
-	}
 }
 
 // multi-GPU helpers: the packed order is the path order of k_raygen

@@ -1,14 +1,15 @@
 // k_trace: closest-hit traversal, intersect() of shaders/framebuffer.comp:423-456, as a persistent
 // wavefront kernel.
 //
-//  * one ray per lane; a wave keeps pulling rays from a global work counter and REFILLS idle lanes
-//    (ballot + mbcnt prefix, one atomic per wave per refill) so that long rays do not strand a wave;
+//  * one ray per lane; a wave keeps pulling 64-ray units from sharded work counters and REFILLS idle lanes
+//    (ballot + mbcnt prefix) so that long rays do not strand a wave;
+//  * a lane alternates between node steps and single-triangle tests; both fetch 64 aligned bytes, so every wave
+//    iteration is one memory round trip in which every active lane makes progress (see k_trace below);
 //  * traversal stack: PT_SHORT_STACK entries per lane in LDS, laid out [level][lane] so that a
 //    wave-wide push/pop is bank-conflict free whatever the per-lane depth; deeper pushes spill to a
 //    per-wave HBM tail (counted in pt_counters.stack_spills; the reference has 16 slots and no check);
 //  * node pairs are siblings: 64 contiguous, 64-byte aligned bytes -> 4 x dwordx4 per lane per step;
-//    a triangle test reads 48 of the 64 bytes (the packed normals / material are only read by the
-//    shading kernel for the one accepted hit);
+//    the packed normals / material of a triangle are only used by the shading kernel for the one accepted hit;
 //  * arithmetic order follows the shader exactly -- the hit index is part of the bit-exact contract.
 #pragma once
 #include "device_math.h"
@@ -17,12 +18,14 @@
 #define PT_SPILL_STACK 48   // 16 + 48 = 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_BLOCK 256
 #define PT_TRACE_WAVES (PT_TRACE_BLOCK / 64)
-// Work distribution: the ray range is cut into 64-ray units; the units are dealt to PT_SHARDS contiguous shards,
-// each with its own counter on its own 128-byte line.  A wave pulls one unit at a time from its home shard and
-// walks on to the next shard when one runs dry, so no single word sees more than total/(64*PT_SHARDS) atomics
-// (one word saturates at ~88 atomics/us on this chip; a single counter made the first version atomic-bound).
+// Work distribution.  A ray queue is cut into PT_SHARDS regions of `cap` slots (cap a multiple of 256); region r
+// holds count[r] live entries at slots [r*cap, r*cap + count[r]).  Every region has its own fill counter and its own
+// work-unit counter, each on a 128-byte line of its own, so no single word sees more than 1/PT_SHARDS of the
+// atomics (one word saturates at ~88 returning atomics/us on this chip: a single queue tail made the first shading
+// kernel atomic-bound at 32k waves per launch, a single work counter did the same to the trace kernel).
+// A trace wave pulls 64-ray units from its home region and walks on to the next region when one runs dry.
 #define PT_SHARDS 64
-#define PT_SHARD_STRIDE 32
+#define PT_SHARD_STRIDE 32   // u32 words between two counters = 128 bytes
 
 struct DevScene {
 	const float4 *nodes;   // node i at nodes[2*i]; allocation is shifted so pairs (2k+1, 2k+2) are 64-B aligned
@@ -38,18 +41,20 @@ struct DevScene {
 
 // device control block shared by the kernels of one context
 struct DevCtl {
-	uint32_t qcount[2];   // live entries of the two path queues
-	uint32_t work;        // unused (kept for layout)
-	uint32_t pad;
-	unsigned long long rays_primary, rays_shadow, rays_bounce, node_steps, tri_tests, stack_spills, paths, pad2;
-	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE]; // trace work counters, zeroed by the kernel before each trace launch
+	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, pad[11];
+	uint32_t qcount[2][PT_SHARDS * PT_SHARD_STRIDE];             // live entries of region r of queue q at [q][r*32]
+	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE];                 // trace work-unit counters, zeroed before each trace launch
+	unsigned long long rays_bounce[PT_SHARDS * (PT_SHARD_STRIDE / 2)]; // per-region statistics, summed by the host
+	unsigned long long rays_shadow[PT_SHARDS * (PT_SHARD_STRIDE / 2)];
 };
 
-// One segment of rays: structure-of-arrays with a common stride.
-//   ray[c*stride + i], c = 0..5 : ro.xyz, rd.xyz        hit[c*stride + i], c = 0..3 : prim, tk, u, v
+// One segment of rays.  Rays are structure-of-arrays with a common stride: ray[c*stride + i], c = 0..5 = ro.xyz,
+// rd.xyz (wave refills read runs of consecutive slots: coalesced).  A hit is ONE 16-byte record per slot,
+// hit[i] = (prim, t_h | kind<<16, u, v): lanes finish at different times, so a hit is written by a lone lane and
+// one dwordx4 store touches one 32-byte sector where four column stores touched four.
 struct RaySeg {
 	const float *ray;
-	uint32_t *hit;
+	uint4 *hit;
 	const uint32_t *valid; // optional: bit0 of valid[i] says the slot holds a ray (shadow segment)
 };
 
@@ -57,12 +62,13 @@ struct TraceArgs {
 	DevScene sc;
 	RaySeg seg[2];
 	uint32_t stride;
-	uint32_t n_fixed;          // ray count per segment when count_ptr == nullptr
-	const uint32_t *count_ptr; // else read on the device (queue length written by the previous kernel)
+	uint32_t cap;              // slots per region
+	uint32_t n_fixed;          // total ray count when count_ptr == nullptr: region r holds clamp(n_fixed - r*cap, 0, cap)
+	const uint32_t *count_ptr; // else count of region r at count_ptr[r * PT_SHARD_STRIDE] (written by the previous kernel)
 	uint32_t n_segs;
 	uint32_t refill_threshold; // refill when at least this many lanes of the wave are idle
 	DevCtl *ctl;
-	uint32_t *zero_on_entry;   // optional word cleared by block 0 (the queue the next shade kernel fills)
+	uint32_t *zero_on_entry;   // optional: region counters of the queue the next shading kernel fills, cleared by block 0
 	uint32_t *spill;           // [gridDim.x * PT_TRACE_WAVES][PT_SPILL_STACK][64]
 };
 
@@ -101,6 +107,19 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 	return -1.0f;
 }
 
+#define PT_CUR_DONE 0xfffffffeu
+
+// Per-lane state machine.  A lane is in one of two modes each iteration:
+//   N  fetch the sibling pair at `cur`, run both slab tests, queue the triangles of the hit leaves as a pending
+//      range [tri_i, tri_end) and pick the next `cur` (descend / push / pop) -- one iteration of while(true), fc:352-418,
+//      minus its triangle loop;
+//   T  test ONE pending triangle (fc:368-378).
+// Both modes fetch 64 aligned bytes through the same four dwordx4 loads, so a wave iteration costs ONE memory round
+// trip whatever mix of modes its lanes are in, and every active lane makes progress every iteration.  (The first
+// version ran the triangle loop inside the node step: a lane with an 8-triangle leaf held 63 others through 8
+// dependent round trips -- VALU lane utilisation 24 %, profiles/r01b.)  The order of operations seen by ONE ray is
+// unchanged: the pending triangles are tested, in order, before the next pair's slab tests read tmax, and the
+// descend/push/pop decision never depended on them (the stack holds node indices only).
 template <bool COUNT>
 __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 {
@@ -109,28 +128,28 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 	uint32_t *const lds = &s_stack[wave][0][lane];
 	uint32_t *const spill = a.spill + ((size_t) (blockIdx.x * PT_TRACE_WAVES + wave) * PT_SPILL_STACK) * 64 + lane;
 
-	const uint32_t n_per_seg = a.count_ptr ? *a.count_ptr : a.n_fixed;
-	const uint32_t total = n_per_seg * a.n_segs;
-	if (blockIdx.x == 0 && threadIdx.x == 0 && a.zero_on_entry) *a.zero_on_entry = 0;
+	if (blockIdx.x == 0 && threadIdx.x < PT_SHARDS && a.zero_on_entry) a.zero_on_entry[threadIdx.x * PT_SHARD_STRIDE] = 0;
 
 	const float4 *__restrict__ nodes = a.sc.nodes;
 	const float4 *__restrict__ tris = a.sc.tris;
+	const uint32_t n_nodes = a.sc.n_nodes, n_tris_total = a.sc.n_tris;
 
 	// per-lane ray state
 	bool active = false;
-	uint32_t slot = 0, seg = 0;
+	uint32_t slot = 0;
 	v3 ro = V(0, 0, 0), rd = V(0, 0, 0), inv = V(0, 0, 0);
 	float tmax = PT_TMAX;
-	uint32_t cur = 1, sp = 0;
+	uint32_t cur = PT_CUR_DONE, sp = 0, tri_i = 0, tri_end = 0;
 	uint32_t best_prim = 0xffffffffu, best_tk = 0;
 	float best_u = 0.0f, best_v = 0.0f;
+	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
 	uint32_t n_steps = 0, n_tests = 0, n_spills = 0;
-	bool exhausted = (total == 0);
 	// wave-uniform work state
-	uint32_t loc_next = 0, loc_end = 0; // the unit this wave is handing out to its lanes
-	const uint32_t total_units = (total + 63u) >> 6;
-	const uint32_t units_per_shard = (total_units + PT_SHARDS - 1u) / PT_SHARDS;
+	bool exhausted = false;
+	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0, lane_seg = 0; // the unit this wave is handing out to its lanes
 	uint32_t shard = (blockIdx.x * PT_TRACE_WAVES + wave) % PT_SHARDS, shards_done = 0;
+	uint32_t shard_count = 0, shard_units = 0;
+	bool shard_known = false;
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill idle lanes
@@ -140,18 +159,31 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 			if (loc_next == loc_end) {
 				bool found = false;
 				while (shards_done < PT_SHARDS) {
-					uint32_t u = 0;
-					if (lane == 0) u = atomicAdd(&a.ctl->shard[shard * PT_SHARD_STRIDE], 1u);
-					u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
-					const uint32_t unit = shard * units_per_shard + u;
-					if (u < units_per_shard && unit < total_units) {
-						loc_next = unit << 6;
-						loc_end = loc_next + 64u < total ? loc_next + 64u : total;
-						found = true;
-						break;
+					if (!shard_known) {
+						uint32_t cnt;
+						if (a.count_ptr) cnt = a.count_ptr[shard * PT_SHARD_STRIDE];
+						else { const uint32_t lo = shard * a.cap; cnt = a.n_fixed > lo ? (a.n_fixed - lo < a.cap ? a.n_fixed - lo : a.cap) : 0u; }
+						shard_count = (uint32_t) __builtin_amdgcn_readfirstlane((int) (cnt < a.cap ? cnt : a.cap));
+						shard_units = (shard_count + 63u) >> 6;
+						shard_known = true;
 					}
-					shard = shard + 1u == PT_SHARDS ? 0u : shard + 1u; // this shard is dry for good: never revisited
+					if (shard_units) {
+						uint32_t u = 0;
+						if (lane == 0) u = atomicAdd(&a.ctl->shard[shard * PT_SHARD_STRIDE], 1u);
+						u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
+						if (u < shard_units * a.n_segs) {
+							loc_seg = u >= shard_units ? 1u : 0u;
+							const uint32_t idx = u - loc_seg * shard_units;
+							const uint32_t base = shard * a.cap;
+							loc_next = base + (idx << 6);
+							loc_end = loc_next + 64u < base + shard_count ? loc_next + 64u : base + shard_count;
+							found = true;
+							break;
+						}
+					}
+					shard = shard + 1u == PT_SHARDS ? 0u : shard + 1u; // this region is dry for good: never revisited
 					shards_done++;
+					shard_known = false;
 				}
 				if (!found) exhausted = true;
 			}
@@ -161,31 +193,45 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 			loc_next += take;
 			if (!active) {
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
-				const uint32_t w = base + rank;
 				if (rank < take) {
-					seg = w >= n_per_seg ? 1u : 0u;
-					slot = w - seg * n_per_seg;
-					const RaySeg &rs = a.seg[seg];
+					slot = base + rank;
+					lane_seg = loc_seg;
+					const RaySeg &rs = a.seg[loc_seg];
 					bool ok = rs.valid ? (rs.valid[slot] & 1u) != 0 : true;
 					if (ok) {
 						const float *r = rs.ray + slot;
 						const uint32_t st = a.stride;
+						const v3 fro = V(r[0], r[st], r[2 * st]);
+						const v3 frd = V(r[3 * st], r[4 * st], r[5 * st]);
+						// Sphere loop of fc:439-453, hoisted in front of the traversal while the full-precision ray is in
+						// registers.  The loop only compares against tmax, so its outcome is: the LAST sphere attaining the
+						// smallest fp16 t wins iff that t <= the traversal's final tmax -- evaluated when the lane retires.
+						sph_tk = 0; sph_prim = 0;
+						{
+							float smax = PT_TMAX;
+							const uint32_t ns = a.sc.n_spheres & 0xffffu; // uint16_t loop counter, fc:439
+							for (uint32_t i = 0; i < ns; i++) {
+								const float4 s = a.sc.spheres[2u * i];
+								const h16 th = to_h16(sphere_t(fro, frd, s));
+								const float ct = (float) th;
+								if (ct >= PT_TMIN && ct <= smax) { smax = ct; sph_prim = i; sph_tk = h_bits(th) | (2u << 16); }
+							}
+						}
 						// fc:437 -- traversal sees the ray rounded to fp16 and widened again
-						ro = V(q16(r[0]), q16(r[st]), q16(r[2 * st]));
-						rd = V(q16(r[3 * st]), q16(r[4 * st]), q16(r[5 * st]));
+						ro = q16(fro);
+						rd = q16(frd);
 						inv = V(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z); // fc:347
 						tmax = PT_TMAX;
-						cur = 1; sp = 0;
+						sp = 0; tri_i = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
-						cur = a.sc.n_nodes >= 3 ? 1u : 0xfffffffeu;
+						cur = n_nodes >= 3u ? 1u : PT_CUR_DONE;
 						active = true;
 					}
 				}
 			}
 		}
-		const unsigned long long act0 = __ballot(active);
-		if (act0 == 0ull) {
+		if (__ballot(active) == 0ull) {
 			if (exhausted) break;
 			continue;
 		}
@@ -193,99 +239,76 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 		// ------------------------------------------------------------------ traverse until enough lanes go idle
 		for (;;) {
 			if (active) {
-				bool done = false;
-				if (cur == 0xfffffffeu) {
-					done = true;
-				} else {
-					// one iteration of while(true), fc:352-418
-					const float4 *p = nodes + 2u * (size_t) cur;
-					const float4 l_lo = p[0], l_hi = p[1], r_lo = p[2], r_hi = p[3];
-					if (COUNT) n_steps++;
-					float le, lx, re, rx;
-					box_pair_test(l_lo, l_hi, ro, inv, tmax, &le, &lx);
-					box_pair_test(r_lo, r_hi, ro, inv, tmax, &re, &rx);
-					bool hit_l = le <= lx, hit_r = re <= rx;
-					const bool leaf_l = l_hi.w > 0.0f, leaf_r = r_hi.w > 0.0f;
-					const uint32_t n_tris = (uint32_t) (hit_l ? l_hi.w : 0.0f) + (uint32_t) (hit_r ? r_hi.w : 0.0f);
-					if (n_tris > 0) {
-						const uint32_t first = (uint32_t) ((hit_l && leaf_l) ? l_lo.w : r_lo.w);
-						for (uint32_t i = 0; i < n_tris; i++) {
-							// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
-							const uint32_t ti = first + i;
-							if (COUNT) n_tests++;
-							if (ti >= a.sc.n_tris) continue;
-							const float4 *tp = tris + 4u * (size_t) ti;
-							const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
-							const v3 v0 = V(d1.x, d1.y, d1.z);
-							const v3 e1 = V(d2.x, d2.y, d2.z) - v0;
-							const v3 e2 = V(d3.x, d3.y, d3.z) - v0;
-							const v3 pv = cross(rd, e2);
-							const float det = dot(e1, pv);
-							const float inv_det = 1.0f / det;
-							const v3 tv = ro - v0;
-							const float u = dot(tv, pv) * inv_det;
-							if (__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f) continue;
+				const bool tmode = tri_i < tri_end;
+				if (tmode || cur != PT_CUR_DONE) {
+					const float4 *p = tmode ? tris + 4u * (size_t) tri_i : nodes + 2u * (size_t) cur;
+					const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+					if (tmode) {
+						// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
+						if (COUNT) n_tests++;
+						const v3 v0 = V(q0.x, q0.y, q0.z);
+						const v3 e1 = V(q1.x, q1.y, q1.z) - v0;
+						const v3 e2 = V(q2.x, q2.y, q2.z) - v0;
+						const v3 pv = cross(rd, e2);
+						const float det = dot(e1, pv);
+						const float inv_det = 1.0f / det;
+						const v3 tv = ro - v0;
+						const float u = dot(tv, pv) * inv_det;
+						if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {
 							const v3 qv = cross(tv, e1);
 							const float v = inv_det * dot(rd, qv);
 							const float t = inv_det * dot(e2, qv);
 							if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
 								const h16 th = to_h16(t);
 								tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
-								best_prim = ti;
+								best_prim = tri_i;
 								best_tk = h_bits(th) | (1u << 16);
 								best_u = u; best_v = v;
 							}
 						}
-						hit_l = hit_l && !leaf_l;
-						hit_r = hit_r && !leaf_r;
-					}
-					if (hit_l) {
-						if (hit_r) {
-							uint32_t first = (uint32_t) l_lo.w, second = (uint32_t) r_lo.w;
-							if (le > re) { const uint32_t tmp = first; first = second; second = tmp; }
-							if (sp < PT_SHORT_STACK) lds[sp * 64u] = second;
-							else if (sp < PT_SHORT_STACK + PT_SPILL_STACK) { spill[(sp - PT_SHORT_STACK) * 64u] = second; n_spills++; }
-							sp++;
-							cur = first;
-						} else {
-							cur = (uint32_t) l_lo.w;
-						}
-					} else if (hit_r) {
-						cur = (uint32_t) r_lo.w;
+						tri_i++;
 					} else {
-						if (sp == 0) done = true;
-						else {
+						if (COUNT) n_steps++;
+						float le, lx, re, rx;
+						box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
+						box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
+						bool hit_l = le <= lx, hit_r = re <= rx;
+						const bool leaf_l = q1.w > 0.0f, leaf_r = q3.w > 0.0f;
+						const uint32_t n_leaf = (uint32_t) (hit_l ? q1.w : 0.0f) + (uint32_t) (hit_r ? q3.w : 0.0f);
+						if (n_leaf > 0u) {
+							tri_i = (uint32_t) ((hit_l && leaf_l) ? q0.w : q2.w); // fc:367
+							tri_end = tri_i + n_leaf;
+							if (tri_end > n_tris_total) tri_end = n_tris_total;   // foreign BVH whose sibling leaves are not contiguous
+							if (tri_i > tri_end) tri_i = tri_end;
+							hit_l = hit_l && !leaf_l;
+							hit_r = hit_r && !leaf_r;
+						}
+						if (hit_l) {
+							if (hit_r) {
+								uint32_t first = (uint32_t) q0.w, second = (uint32_t) q2.w;
+								if (le > re) { const uint32_t tmp = first; first = second; second = tmp; }
+								if (sp < PT_SHORT_STACK) lds[sp * 64u] = second;
+								else if (sp < PT_SHORT_STACK + PT_SPILL_STACK) { spill[(sp - PT_SHORT_STACK) * 64u] = second; n_spills++; }
+								sp++;
+								cur = first;
+							} else {
+								cur = (uint32_t) q0.w;
+							}
+						} else if (hit_r) {
+							cur = (uint32_t) q2.w;
+						} else if (sp == 0u) {
+							cur = PT_CUR_DONE;
+						} else {
 							sp--;
 							cur = sp < PT_SHORT_STACK ? lds[sp * 64u] : spill[(sp - PT_SHORT_STACK) * 64u];
 						}
+						if (cur != PT_CUR_DONE && cur + 1u >= n_nodes) cur = PT_CUR_DONE; // corrupt index: stop rather than fault
 					}
-					if (!done && cur + 1u >= a.sc.n_nodes) done = true; // corrupt index: stop rather than fault
 				}
-				if (done) {
-					// sphere loop, fc:439-453, with the full-precision ray
-					if (a.sc.n_spheres) {
-						const float *r = a.seg[seg].ray + slot;
-						const uint32_t st = a.stride;
-						const v3 fro = V(r[0], r[st], r[2 * st]);
-						const v3 frd = V(r[3 * st], r[4 * st], r[5 * st]);
-						const uint32_t ns = a.sc.n_spheres & 0xffffu;
-						for (uint32_t i = 0; i < ns; i++) {
-							const float4 s = a.sc.spheres[2u * i];
-							const h16 th = to_h16(sphere_t(fro, frd, s));
-							const float ct = (float) th;
-							if (ct >= PT_TMIN && ct <= tmax) {
-								tmax = ct;
-								best_prim = i;
-								best_tk = h_bits(th) | (2u << 16);
-							}
-						}
-					}
-					uint32_t *h = a.seg[seg].hit + slot;
-					const uint32_t st = a.stride;
-					h[0] = best_prim;
-					h[st] = best_tk;
-					h[2 * st] = __float_as_uint(best_u);
-					h[3 * st] = __float_as_uint(best_v);
+				if (tri_i >= tri_end && cur == PT_CUR_DONE) {
+					// retire: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax)
+					if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
+					a.seg[lane_seg].hit[slot] = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
 					active = false;
 				}
 			}

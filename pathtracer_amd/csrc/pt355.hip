@@ -36,7 +36,10 @@ struct pt_ctx {
 	float cam[12];
 
 	// queues
-	uint32_t n_paths = 0, stride = 0;
+	uint32_t n_paths = 0;   // paths per frame = pixels this rank owns
+	uint32_t max_batch = 1; // frames traced together (pt_config.max_batch)
+	uint32_t stride = 0, cap = 0, blocks_per_region = 0;
+	float4 *sample = nullptr;
 	void *queue_alloc = nullptr;
 	PathQ q[2];
 	DevCtl *ctl = nullptr;
@@ -138,7 +141,7 @@ void carve_queue(PathQ &q, char *&p, uint32_t stride)
 	q.thr = (float *) take(3); q.col = (float *) take(3);
 	q.ray = (float *) take(6); q.sray = (float *) take(6);
 	q.nee = (float *) take(8); q.bs = (float *) take(5);
-	q.hit = (uint32_t *) take(4); q.shit = (uint32_t *) take(4);
+	q.hit = (uint4 *) take(4); q.shit = (uint4 *) take(4);
 }
 const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
 
@@ -163,11 +166,12 @@ TraceArgs queue_trace_args(pt_ctx *c, uint32_t qi, bool with_shadow)
 	ta.seg[0].ray = c->q[qi].ray; ta.seg[0].hit = c->q[qi].hit; ta.seg[0].valid = nullptr;
 	ta.seg[1].ray = c->q[qi].sray; ta.seg[1].hit = c->q[qi].shit; ta.seg[1].valid = c->q[qi].meta;
 	ta.stride = c->stride;
-	ta.count_ptr = &c->ctl->qcount[qi];
+	ta.cap = c->cap;
+	ta.count_ptr = c->ctl->qcount[qi];
 	ta.n_segs = with_shadow ? 2 : 1;
 	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = c->ctl;
-	ta.zero_on_entry = &c->ctl->qcount[qi ^ 1u];
+	ta.zero_on_entry = c->ctl->qcount[qi ^ 1u];
 	ta.spill = c->spill;
 	return ta;
 }
@@ -225,8 +229,19 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	c->trace_grid = c->n_cu * blocks_per_cu;
 
 	c->n_paths = own_tiles(cfg->width, cfg->height, cfg->partition, cfg->rank, world) * 64u;
-	c->stride = (c->n_paths + 255u) & ~255u;
-	if (c->stride == 0) c->stride = 256;
+	// Frames in flight per set of launches.  A trace launch costs ~0.25 ms of ramp-up and tail whatever its size
+	// (DESIGN.md "Batching"), so a batch is made as large as a modest memory budget allows: <= 2^25 paths (~12 GB).
+	c->max_batch = cfg->max_batch ? cfg->max_batch : 8u;
+	if (c->max_batch > PT_MAX_BATCH) c->max_batch = PT_MAX_BATCH;
+	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 25)) c->max_batch--;
+	if (const char *e = getenv("PT355_BATCH")) { int v = atoi(e); if (v >= 1 && v <= PT_MAX_BATCH) c->max_batch = (uint32_t) v; }
+	// queue geometry: PT_SHARDS regions of `cap` slots, cap a whole number of shading blocks (kernels_trace.h)
+	{
+		const uint32_t n_blocks = (uint32_t) (((uint64_t) c->max_batch * c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK);
+		c->blocks_per_region = n_blocks ? (n_blocks + PT_SHARDS - 1) / PT_SHARDS : 1;
+		c->cap = c->blocks_per_region * PT_SHADE_BLOCK;
+		c->stride = c->cap * PT_SHARDS;
+	}
 	const size_t qbytes = (size_t) kQueueCols * c->stride * 4;
 	CREATE_TRY(hipMalloc(&c->queue_alloc, 2 * qbytes));
 	CREATE_TRY(hipMemsetAsync(c->queue_alloc, 0, 2 * qbytes, c->stream));
@@ -236,6 +251,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	CREATE_TRY(hipMalloc((void **) &c->ctl, sizeof(DevCtl)));
 	CREATE_TRY(hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
 	CREATE_TRY(hipMalloc((void **) &c->spill, (size_t) c->trace_grid * PT_TRACE_WAVES * PT_SPILL_STACK * 64 * 4));
+	CREATE_TRY(hipMalloc((void **) &c->sample, ((size_t) c->max_batch * c->n_paths + 1) * 16));
 	const size_t fb_bytes = (size_t) cfg->width * cfg->height * 16;
 	CREATE_TRY(hipMalloc((void **) &c->fb, fb_bytes));
 	CREATE_TRY(hipMemsetAsync(c->fb, 0, fb_bytes, c->stream));
@@ -257,6 +273,7 @@ int pt_destroy(pt_ctx *c)
 	if (c->ctl) hipFree(c->ctl);
 	if (c->spill) hipFree(c->spill);
 	if (c->fb) hipFree(c->fb);
+	if (c->sample) hipFree(c->sample);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
 	return PT_OK;
@@ -343,30 +360,38 @@ int pt_set_camera(pt_ctx *c, const float cam[12])
 	return PT_OK;
 }
 
-int pt_render_frame(pt_ctx *c, const uint32_t frame_data[4])
+// n_batch consecutive frames through one set of launches: raygen, (trace, shade) x (bounces + 1), resolve
+static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const uint32_t *seeds, uint32_t bounces)
 {
-	if (!c || !frame_data) return PT_EINVAL;
-	if (!c->have_scene || !c->have_camera) return fail(c, PT_ESTATE, "pt_render_frame: upload a scene and set the camera first");
-	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	if (c->n_paths == 0) { c->frames++; return PT_OK; }
+	if (c->n_paths == 0) { c->frames += n_batch; return PT_OK; }
 	if (c->pending.size() > 4096) { int rc = drain_events(c); if (rc) return rc; }
 
 	ShadeArgs sa;
 	memset(&sa, 0, sizeof sa);
 	sa.sc = c->sc;
 	sa.stride = c->stride;
+	sa.cap = c->cap;
+	sa.blocks_per_region = c->blocks_per_region;
 	sa.ctl = c->ctl;
 	memcpy(sa.cam, c->cam, sizeof sa.cam);
 	sa.width = c->cfg.width; sa.height = c->cfg.height;
-	sa.seed = frame_data[0]; sa.frame = frame_data[1]; sa.bounces = frame_data[2];
+	sa.bounces = bounces;
 	sa.flags = c->cfg.flags;
+	sa.sample = c->sample;
 	sa.fb = c->fb;
-	sa.rank = c->cfg.rank; sa.world = c->cfg.world; sa.partition = c->cfg.partition; sa.n_paths = c->n_paths;
-	const dim3 sgrid((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock(PT_SHADE_BLOCK);
+	sa.n_batch = n_batch; sa.first_frame = first_frame; sa.n_paths_frame = c->n_paths;
+	const uint32_t n_total = n_batch * c->n_paths;
+	sa.per_region = (((n_total + 63u) / 64u + PT_SHARDS - 1) / PT_SHARDS) * 64u; // whole 64-ray units, <= cap
+	for (uint32_t i = 0; i < n_batch; i++) sa.seeds[i] = seeds[i];
+	sa.rank = c->cfg.rank; sa.world = c->cfg.world; sa.partition = c->cfg.partition;
+	const dim3 sblock(PT_SHADE_BLOCK);
+	// shading blocks that cover the occupied prefix of every region would need a 2-D launch; regions past the batch's
+	// own size are empty and their blocks return after one load, so the grid simply covers every slot
+	const dim3 sgrid(c->stride / PT_SHADE_BLOCK);
 
 	sa.out = c->q[0];
 	begin_timed(c, 1);
-	hipLaunchKernelGGL(k_raygen, sgrid, sblock, 0, c->stream, sa);
+	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, c->stream, sa);
 	end_timed(c);
 	uint32_t qi = 0;
 	for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
@@ -378,18 +403,32 @@ int pt_render_frame(pt_ctx *c, const uint32_t frame_data[4])
 		end_timed(c);
 		qi ^= 1u;
 	}
+	begin_timed(c, 1);
+	hipLaunchKernelGGL(k_resolve, dim3((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, c->stream, sa);
+	end_timed(c);
 	HIP_TRY(c, hipGetLastError());
-	c->frames++;
+	c->frames += n_batch;
 	return PT_OK;
+}
+
+int pt_render_frame(pt_ctx *c, const uint32_t frame_data[4])
+{
+	if (!c || !frame_data) return PT_EINVAL;
+	if (!c->have_scene || !c->have_camera) return fail(c, PT_ESTATE, "pt_render_frame: upload a scene and set the camera first");
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	return render_batch(c, frame_data[1], 1, &frame_data[0], frame_data[2]);
 }
 
 int pt_render(pt_ctx *c, uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces)
 {
 	if (!c || (n_frames && !seeds)) return PT_EINVAL;
-	for (uint32_t f = 0; f < n_frames; f++) {
-		const uint32_t fd[4] = {seeds[f], first_frame + f, bounces, 0};
-		int rc = pt_render_frame(c, fd);
+	if (!c->have_scene || !c->have_camera) return fail(c, PT_ESTATE, "pt_render: upload a scene and set the camera first");
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	for (uint32_t f = 0; f < n_frames;) {
+		const uint32_t nb = n_frames - f < c->max_batch ? n_frames - f : c->max_batch;
+		int rc = render_batch(c, first_frame + f, nb, seeds + f, bounces);
 		if (rc) return rc;
+		f += nb;
 	}
 	return PT_OK;
 }
@@ -438,8 +477,9 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	TraceArgs ta;
 	memset(&ta, 0, sizeof ta);
 	ta.sc = c->sc;
-	ta.seg[0].ray = (const float *) ray6_dev; ta.seg[0].hit = (uint32_t *) hit4_dev;
+	ta.seg[0].ray = (const float *) ray6_dev; ta.seg[0].hit = (uint4 *) hit4_dev;
 	ta.stride = n; ta.n_fixed = n; ta.n_segs = 1;
+	ta.cap = (((n + 63u) / 64u + PT_SHARDS - 1) / PT_SHARDS) * 64u; // whole 64-ray units per region
 	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = c->ctl;
 	ta.spill = c->spill;
@@ -471,13 +511,14 @@ int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, ui
 	if (rc) return rc;
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_trace_closest: %s", hipGetErrorString(e));
 	for (uint32_t i = 0; i < n; i++) {
-		const uint32_t tk = hit[(size_t) n + i];
+		const uint32_t *h = &hit[4 * (size_t) i];
+		const uint32_t tk = h[1];
 		kind[i] = (uint8_t) (tk >> 16);
-		prim[i] = kind[i] ? hit[i] : 0xffffffffu;
+		prim[i] = kind[i] ? h[0] : 0xffffffffu;
 		t_h[i] = kind[i] ? (uint16_t) (tk & 0xffffu) : 0;
 		if (uv) {
-			memcpy(&uv[2 * (size_t) i], &hit[(size_t) 2 * n + i], 4);
-			memcpy(&uv[2 * (size_t) i + 1], &hit[(size_t) 3 * n + i], 4);
+			memcpy(&uv[2 * (size_t) i], &h[2], 4);
+			memcpy(&uv[2 * (size_t) i + 1], &h[3], 4);
 			if (kind[i] != 1) uv[2 * (size_t) i] = uv[2 * (size_t) i + 1] = 0.0f;
 		}
 	}
@@ -495,7 +536,11 @@ int pt_get_counters(pt_ctx *c, pt_counters *out)
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	memset(out, 0, sizeof *out);
 	out->frames = c->frames;
-	out->paths = h.paths; out->rays_primary = h.rays_primary; out->rays_shadow = h.rays_shadow; out->rays_bounce = h.rays_bounce;
+	out->paths = h.paths; out->rays_primary = h.rays_primary;
+	for (uint32_t r = 0; r < PT_SHARDS; r++) {
+		out->rays_shadow += h.rays_shadow[r * (PT_SHARD_STRIDE / 2)];
+		out->rays_bounce += h.rays_bounce[r * (PT_SHARD_STRIDE / 2)];
+	}
 	out->node_steps = h.node_steps; out->tri_tests = h.tri_tests; out->stack_spills = h.stack_spills;
 	out->ms_trace = c->ms_trace; out->ms_shade = c->ms_shade; out->trace_launches = c->trace_launches;
 	return PT_OK;
@@ -564,11 +609,11 @@ int pt_debug_read_queue(pt_ctx *c, uint32_t queue, uint32_t field, void *out, si
 	const size_t need = (size_t) cols[field] * c->stride;
 	if (n_words != need) return fail(c, PT_EINVAL, "pt_debug_read_queue: field %u needs %zu words", field, need);
 	HIP_TRY(c, hipMemcpyAsync(out, base[field], need * 4, hipMemcpyDeviceToHost, c->stream));
-	uint32_t qc[2];
-	HIP_TRY(c, hipMemcpyAsync(qc, c->ctl->qcount, 8, hipMemcpyDeviceToHost, c->stream));
+	static uint32_t qc[PT_SHARDS * PT_SHARD_STRIDE];
+	HIP_TRY(c, hipMemcpyAsync(qc, c->ctl->qcount[queue], sizeof qc, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if (stride) *stride = c->stride;
-	if (count) *count = qc[queue];
+	if (count) { *count = 0; for (uint32_t r = 0; r < PT_SHARDS; r++) *count += qc[r * PT_SHARD_STRIDE]; }
 	return PT_OK;
 }
 

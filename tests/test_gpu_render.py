@@ -49,3 +49,33 @@ def test_retiring_dead_paths_keeps_the_image(pt, ol):
     same, rmse, dmax = _report(a, ref)
     assert same == 1.0
     assert cnt_a["rays_bounce"] <= ocnt["rays_bounce"]
+
+
+def test_batch_size_does_not_change_the_image(pt):
+    """Frames in flight per launch set (pt_config.max_batch) is a scheduling choice: samples are blended in frame order."""
+    scene = pt.Scene.bunny(freq=10, target_tris=0, spheres=True)
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 7)
+    imgs = []
+    for mb in (1, 3, 8, 16):
+        c = pt.PathTracer(72, 40, max_batch=mb)
+        try:
+            c.upload_scene(scene)
+            c.set_camera(cam)
+            c.render(0, seeds, 5)
+            imgs.append(c.read_framebuffer())
+        finally:
+            c.close()
+    c = pt.PathTracer(72, 40)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(cam)
+        for f in range(7):
+            c.render_frame(int(seeds[f]), f, 5)   # the reference's own call pattern: one dispatch per frame
+        imgs.append(c.read_framebuffer())
+        c.render(7, pt.frame_seeds(7, 2), 5)      # and resuming an accumulation
+        more = c.read_framebuffer()
+    finally:
+        c.close()
+    for im in imgs[1:]:
+        assert np.array_equal(imgs[0].view(np.uint32), im.view(np.uint32))
+    assert not np.array_equal(more, imgs[0])
