@@ -225,8 +225,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 						sp = 0; tri_i = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
-						cur = n_nodes >= 3u ? 1u : PT_CUR_DONE;
-						active = true;
+						if (n_nodes >= 3u) { cur = 1u; active = true; }
+						else a.seg[lane_seg].hit[slot] = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
 					}
 				}
 			}
@@ -238,72 +238,76 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 
 		// ------------------------------------------------------------------ traverse until enough lanes go idle
 		for (;;) {
+			// every active lane has work: pending triangles (T) or a node pair to visit (N); lanes retire at once
+			const bool tmode = active && tri_i < tri_end;
+			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
+			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form: the kernel is
+			// bound by dependent round trips, not by VALU issue -- DESIGN.md "What was tried".)
 			if (active) {
-				const bool tmode = tri_i < tri_end;
-				if (tmode || cur != PT_CUR_DONE) {
-					const float4 *p = tmode ? tris + 4u * (size_t) tri_i : nodes + 2u * (size_t) cur;
-					const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-					if (tmode) {
-						// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
-						if (COUNT) n_tests++;
-						const v3 v0 = V(q0.x, q0.y, q0.z);
-						const v3 e1 = V(q1.x, q1.y, q1.z) - v0;
-						const v3 e2 = V(q2.x, q2.y, q2.z) - v0;
-						const v3 pv = cross(rd, e2);
-						const float det = dot(e1, pv);
-						const float inv_det = 1.0f / det;
-						const v3 tv = ro - v0;
-						const float u = dot(tv, pv) * inv_det;
-						if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {
-							const v3 qv = cross(tv, e1);
-							const float v = inv_det * dot(rd, qv);
-							const float t = inv_det * dot(e2, qv);
-							if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
-								const h16 th = to_h16(t);
-								tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
-								best_prim = tri_i;
-								best_tk = h_bits(th) | (1u << 16);
-								best_u = u; best_v = v;
-							}
+				const float4 *p = tmode ? tris + 4u * (size_t) tri_i : nodes + 2u * (size_t) cur;
+				float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
+				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
+				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
+				if (tmode) {
+					// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
+					if (COUNT) n_tests++;
+					const v3 v0 = V(q0.x, q0.y, q0.z);
+					const v3 e1 = V(q1.x, q1.y, q1.z) - v0;
+					const v3 e2 = V(q2.x, q2.y, q2.z) - v0;
+					const v3 pv = cross(rd, e2);
+					const float det = dot(e1, pv);
+					const float inv_det = 1.0f / det;
+					const v3 tv = ro - v0;
+					const float u = dot(tv, pv) * inv_det;
+					if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {
+						const v3 qv = cross(tv, e1);
+						const float v = inv_det * dot(rd, qv);
+						const float t = inv_det * dot(e2, qv);
+						if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
+							const h16 th = to_h16(t);
+							tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
+							best_prim = tri_i;
+							best_tk = h_bits(th) | (1u << 16);
+							best_u = u; best_v = v;
 						}
-						tri_i++;
-					} else {
-						if (COUNT) n_steps++;
-						float le, lx, re, rx;
-						box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
-						box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
-						bool hit_l = le <= lx, hit_r = re <= rx;
-						const bool leaf_l = q1.w > 0.0f, leaf_r = q3.w > 0.0f;
-						const uint32_t n_leaf = (uint32_t) (hit_l ? q1.w : 0.0f) + (uint32_t) (hit_r ? q3.w : 0.0f);
-						if (n_leaf > 0u) {
-							tri_i = (uint32_t) ((hit_l && leaf_l) ? q0.w : q2.w); // fc:367
-							tri_end = tri_i + n_leaf;
-							if (tri_end > n_tris_total) tri_end = n_tris_total;   // foreign BVH whose sibling leaves are not contiguous
-							if (tri_i > tri_end) tri_i = tri_end;
-							hit_l = hit_l && !leaf_l;
-							hit_r = hit_r && !leaf_r;
-						}
-						if (hit_l) {
-							if (hit_r) {
-								uint32_t first = (uint32_t) q0.w, second = (uint32_t) q2.w;
-								if (le > re) { const uint32_t tmp = first; first = second; second = tmp; }
-								if (sp < PT_SHORT_STACK) lds[sp * 64u] = second;
-								else if (sp < PT_SHORT_STACK + PT_SPILL_STACK) { spill[(sp - PT_SHORT_STACK) * 64u] = second; n_spills++; }
-								sp++;
-								cur = first;
-							} else {
-								cur = (uint32_t) q0.w;
-							}
-						} else if (hit_r) {
-							cur = (uint32_t) q2.w;
-						} else if (sp == 0u) {
-							cur = PT_CUR_DONE;
-						} else {
-							sp--;
-							cur = sp < PT_SHORT_STACK ? lds[sp * 64u] : spill[(sp - PT_SHORT_STACK) * 64u];
-						}
-						if (cur != PT_CUR_DONE && cur + 1u >= n_nodes) cur = PT_CUR_DONE; // corrupt index: stop rather than fault
 					}
+					tri_i++;
+				} else {
+					if (COUNT) n_steps++;
+					float le, lx, re, rx;
+					box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
+					box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
+					const bool in_l = le <= lx, in_r = re <= rx;
+					const bool leaf_l = q1.w > 0.0f, leaf_r = q3.w > 0.0f;
+					const uint32_t c_l = (uint32_t) q0.w, c_r = (uint32_t) q2.w; // first child, or first triangle of a leaf
+					// fc:364-382: triangles of the hit leaves become the pending range
+					const uint32_t n_leaf = (in_l ? (uint32_t) q1.w : 0u) + (in_r ? (uint32_t) q3.w : 0u);
+					const uint32_t t_first = (in_l && leaf_l) ? c_l : c_r;
+					uint32_t t_end = t_first + n_leaf;
+					t_end = t_end < n_tris_total ? t_end : n_tris_total; // foreign BVH whose sibling leaves are not contiguous
+					tri_i = n_leaf ? (t_first < t_end ? t_first : t_end) : tri_i;
+					tri_end = n_leaf ? t_end : tri_end;
+					// fc:384-418, as selects: descend into the nearer hit inner child, push the farther, else pop
+					const bool go_l = in_l && !leaf_l, go_r = in_r && !leaf_r;
+					const bool both = go_l && go_r, any = go_l || go_r;
+					const bool r_first = le > re; // tie -> left first
+					const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
+					uint32_t next = both ? nearer : (go_l ? c_l : c_r);
+					if (both) {
+						if (sp < PT_SHORT_STACK) lds[sp * 64u] = farther;
+						else if (sp < PT_SHORT_STACK + PT_SPILL_STACK) { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; }
+						sp++;
+					}
+					if (!any) {
+						next = PT_CUR_DONE;
+						if (sp != 0u) {
+							sp--;
+							next = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
+							if (sp >= PT_SHORT_STACK) next = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
+						}
+					}
+					cur = (next != PT_CUR_DONE && next + 1u >= n_nodes) ? PT_CUR_DONE : next; // corrupt index: stop rather than fault
 				}
 				if (tri_i >= tri_end && cur == PT_CUR_DONE) {
 					// retire: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax)

@@ -19,5 +19,5 @@ pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_
 pass tc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-python3 tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/prof_summary.py $OUT $TAG > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

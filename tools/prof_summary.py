@@ -2,11 +2,13 @@
 """Condenses the rocprofv3 CSVs written by tools/prof.sh into one per-kernel table (mean per dispatch)."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 
 
 def short(name):
@@ -51,3 +53,23 @@ for k in sorted(acc):
     if g("FETCH_SIZE") is not None or g("WRITE_SIZE") is not None:
         f_, w_ = g("FETCH_SIZE") or 0.0, g("WRITE_SIZE") or 0.0
         print(f"   -> HBM-side traffic per dispatch: 2*FETCH_SIZE {2 * f_ * 1024 / 1e6:9.3f} MB + WRITE_SIZE {w_ * 1024 / 1e6:9.3f} MB  (gfx950: FETCH_SIZE counts 64 B per 128-B request)")
+
+# ---- machine-readable HBM-side traffic per launch for bench.py's roofline.traffic (same workload as ptbench's default)
+plain = {}
+try:
+    plain = json.loads(open(os.path.join(out, "plain.json")).read().strip().splitlines()[-1])
+except Exception:
+    pass
+kern = {}
+for k in acc:
+    f_ = acc[k].get("FETCH_SIZE", 0.0) / max(cnt[k].get("FETCH_SIZE", 1), 1)
+    w_ = acc[k].get("WRITE_SIZE", 0.0) / max(cnt[k].get("WRITE_SIZE", 1), 1)
+    if "FETCH_SIZE" in acc[k] or "WRITE_SIZE" in acc[k]:
+        kern[k] = {"fetch_size_kb": f_, "write_size_kb": w_, "hbm_bytes_per_launch": (2.0 * f_ + w_) * 1024.0,
+                   "launches_profiled": cnt[k].get("FETCH_SIZE", 0)}
+if "k_trace" in kern and plain.get("trace_launches"):
+    kern["k_trace"]["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
+if kern:
+    json.dump({"workload": "bunny-1920x1080-b5", "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+               "over pathtracer_amd/ptbench; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+               "kernels": kern}, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
