@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=0, help="frames traced per launch set (0 = library default)")
     ap.add_argument("--trace-dead-paths", action="store_true", help="trace zero-throughput paths like the reference does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=16)
+    ap.add_argument("--cpu-frames", type=int, default=48)
     args = ap.parse_args()
 
     import numpy as np
