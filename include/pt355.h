@@ -33,8 +33,13 @@ extern "C" {
 typedef struct pt_ctx pt_ctx;
 
 /* pt_config.flags */
-#define PT_FLAG_SHADOW_ANYHIT      1u /* NEE visibility by any-hit traversal (fast mode). Default (0) is the
-                                         reference's closest-hit + point compare, framebuffer.comp:970-974. */
+/* NEE visibility.  The reference traces a shadow ray to its CLOSEST hit and compares that point with the light sample,
+ * one-sided per component (framebuffer.comp:970-974).  Default: the same verdict for every ray, but the traversal
+ * stops at the first hit that already decides it (a hit that loses the compare on a component the ray advances
+ * along cannot be rescued by a closer one) -- the image is bit-identical to the full traversal's. */
+#define PT_FLAG_SHADOW_ANYHIT      1u /* fast mode: ANY hit at least 0.02 in front of the light sample occludes it; this ignores
+                                         the one-sided quirk of the compare, so the image differs where that quirk leaks light */
+#define PT_FLAG_SHADOW_FULL_TRAVERSAL 8u /* always traverse to the closest hit (like-for-like work counters against the oracle) */
 #define PT_FLAG_TRACE_DEAD_PATHS   2u /* keep tracing paths whose throughput is exactly 0 (the reference does,
                                          framebuffer.comp:899-1078); default retires them: same image, fewer rays */
 #define PT_FLAG_COUNT_TRAVERSAL    4u /* accumulate node-pair visits / triangle tests (slower; for roofline inputs) */

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libpt355.so")
 PT_FLAG_SHADOW_ANYHIT = 1
 PT_FLAG_TRACE_DEAD_PATHS = 2
 PT_FLAG_COUNT_TRAVERSAL = 4
+PT_FLAG_SHADOW_FULL_TRAVERSAL = 8
 PT_PARTITION_TILES = 0
 PT_PARTITION_FULL = 1
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_SPECULAR_METAL = -1, 0, 1, 2

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 				v3 direct = V(0.0f, 0.0f, 0.0f);
 				const uint4 srec = a.in.shit[i];
 				const uint32_t sp_ = srec.x, stk = srec.y;
-				if ((stk >> 16) != 0u) {
+				if ((stk >> 16) != 0u && (stk >> 16) != 3u) { // kind 3: an any-hit traversal already found an occluder
 					const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
 					const float su = __uint_as_float(srec.z), sv = __uint_as_float(srec.w);
 					const HitRec sh = hit_attributes(sc, sp_, stk, su, sv, sro, srd);

@@ -56,6 +56,7 @@ struct RaySeg {
 	const float *ray;
 	uint4 *hit;
 	const uint32_t *valid; // optional: bit0 of valid[i] says the slot holds a ray (shadow segment)
+	const float *target;   // optional (shadow segment): target[c*stride + i], c = 0..2 = the light sample y_nee the ray aims at
 };
 
 struct TraceArgs {
@@ -67,6 +68,7 @@ struct TraceArgs {
 	const uint32_t *count_ptr; // else count of region r at count_ptr[r * PT_SHARD_STRIDE] (written by the previous kernel)
 	uint32_t n_segs;
 	uint32_t refill_threshold; // refill when at least this many lanes of the wave are idle
+	uint32_t shadow_mode;      // PT_SHADOW_* for rays that carry a target
 	DevCtl *ctl;
 	uint32_t *zero_on_entry;   // optional: region counters of the queue the next shading kernel fills, cleared by block 0
 	uint32_t *spill;           // [gridDim.x * PT_TRACE_WAVES][PT_SPILL_STACK][64]
@@ -109,6 +111,29 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 
 #define PT_CUR_DONE 0xfffffffeu
 
+// Shadow rays (fc:970-974) are judged by the shading kernel from the CLOSEST hit: the light sample is visible iff
+// every component of y_nee - (ro + rd * t_hit) is < 0.01 (one-sided).
+#define PT_SHADOW_FULL   0u // traverse to the closest hit like the reference, whatever is found on the way
+#define PT_SHADOW_EXACT  1u // stop at the first hit that already decides the compare (below): same image, less work
+#define PT_SHADOW_ANYHIT 2u // also stop at any hit at least 0.02 in front of the light sample and call it occluded
+                            // (kind 3): ignores the one-sided quirk, so the image differs where that quirk leaks light
+
+// Largest fp16 t for which the compare is already lost on component k (rd_k > 0): y - (ro + rd*t) >= 0.01.
+// fp32 multiply, add and subtract are monotone, so every t' <= t loses too: once a hit with t <= this bound is
+// accepted, no closer hit (triangle or sphere) can make the sample visible.  -inf when there is no such t.
+PT_DEV float shadow_kill_component(float y, float ro, float rd)
+{
+	if (!(rd > 0.0f)) return -__builtin_inff();
+	float cand = (float) to_h16(((y - ro) - PT_FLOAT_COMPARE) / rd);
+	// the division is only a guess: step down in fp16 until the shading kernel's own expression confirms it
+	for (int i = 0; i < 3; i++) {
+		if ((y - (ro + rd * cand)) >= PT_FLOAT_COMPARE) return cand;
+		cand = (float) h_from_bits(h_bits(to_h16(cand)) - (cand > 0.0f ? 1u : 0u));
+		if (!(cand > 0.0f)) break;
+	}
+	return -__builtin_inff();
+}
+
 // Per-lane state machine.  A lane is in one of two modes each iteration:
 //   N  fetch the sibling pair at `cur`, run both slab tests, queue the triangles of the hit leaves as a pending
 //      range [tri_i, tri_end) and pick the next `cur` (descend / push / pop) -- one iteration of while(true), fc:352-418,
@@ -121,7 +146,7 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 // unchanged: the pending triangles are tested, in order, before the next pair's slab tests read tmax, and the
 // descend/push/pop decision never depended on them (the stack holds node indices only).
 template <bool COUNT>
-__global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 {
 	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK][64];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -143,6 +168,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 	uint32_t best_prim = 0xffffffffu, best_tk = 0;
 	float best_u = 0.0f, best_v = 0.0f;
 	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
+	float t_kill = -__builtin_inff();  // shadow rays: an accepted hit with t <= t_kill ends the traversal
 	uint32_t n_steps = 0, n_tests = 0, n_spills = 0;
 	// wave-uniform work state
 	bool exhausted = false;
@@ -217,6 +243,22 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 								if (ct >= PT_TMIN && ct <= smax) { smax = ct; sph_prim = i; sph_tk = h_bits(th) | (2u << 16); }
 							}
 						}
+						// shadow rays: how early may the traversal stop?
+						t_kill = -__builtin_inff();
+						bool occluded_now = false;
+						if (rs.target && a.shadow_mode != PT_SHADOW_FULL) {
+							const float *tg = rs.target + slot;
+							const v3 y = V(tg[0], tg[st], tg[2 * st]);
+							t_kill = fmax_(shadow_kill_component(y.x, fro.x, frd.x),
+							               fmax_(shadow_kill_component(y.y, fro.y, frd.y), shadow_kill_component(y.z, fro.z, frd.z)));
+							if (a.shadow_mode == PT_SHADOW_ANYHIT) {
+								const v3 d = y - fro;
+								const float t_any = (float) to_h16(__builtin_sqrtf(dot(d, d)) - 2.0f * PT_FLOAT_COMPARE);
+								t_kill = fmax_(t_kill, t_any - 0.01f * t_any); // fp16 rounding of t_any may round up: stay clear of the light
+							}
+							// a sphere that close already decides it: the final hit can only be as close or closer
+							occluded_now = sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= t_kill;
+						}
 						// fc:437 -- traversal sees the ray rounded to fp16 and widened again
 						ro = q16(fro);
 						rd = q16(frd);
@@ -225,7 +267,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 						sp = 0; tri_i = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
-						if (n_nodes >= 3u) { cur = 1u; active = true; }
+						if (occluded_now) {
+							if (a.shadow_mode == PT_SHADOW_ANYHIT) sph_tk = (sph_tk & 0xffffu) | (3u << 16);
+							a.seg[lane_seg].hit[slot] = make_uint4(sph_prim, sph_tk, 0u, 0u);
+						} else if (n_nodes >= 3u) { cur = 1u; active = true; }
 						else a.seg[lane_seg].hit[slot] = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
 					}
 				}
@@ -270,6 +315,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK) void k_trace(TraceArgs a)
 							best_prim = tri_i;
 							best_tk = h_bits(th) | (1u << 16);
 							best_u = u; best_v = v;
+							if (tmax <= t_kill) { // shadow ray decided: nothing closer can change the verdict
+								tri_i = tri_end - 1u; cur = PT_CUR_DONE; sph_tk = 0u;
+								if (a.shadow_mode == PT_SHADOW_ANYHIT) best_tk = (best_tk & 0xffffu) | (3u << 16);
+							}
 						}
 					}
 					tri_i++;

@@ -165,6 +165,9 @@ TraceArgs queue_trace_args(pt_ctx *c, uint32_t qi, bool with_shadow)
 	ta.sc = c->sc;
 	ta.seg[0].ray = c->q[qi].ray; ta.seg[0].hit = c->q[qi].hit; ta.seg[0].valid = nullptr;
 	ta.seg[1].ray = c->q[qi].sray; ta.seg[1].hit = c->q[qi].shit; ta.seg[1].valid = c->q[qi].meta;
+	ta.seg[1].target = c->q[qi].nee + 5 * (size_t) c->stride;
+	ta.shadow_mode = (c->cfg.flags & PT_FLAG_SHADOW_ANYHIT) ? PT_SHADOW_ANYHIT
+	               : (c->cfg.flags & PT_FLAG_SHADOW_FULL_TRAVERSAL) ? PT_SHADOW_FULL : PT_SHADOW_EXACT;
 	ta.stride = c->stride;
 	ta.cap = c->cap;
 	ta.count_ptr = c->ctl->qcount[qi];
@@ -193,7 +196,6 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	if (cfg->partition > PT_PARTITION_FULL) return fail(nullptr, PT_EINVAL, "pt_create: unknown partition %u", cfg->partition);
 	const uint32_t world = cfg->world ? cfg->world : 1;
 	if (cfg->rank >= world) return fail(nullptr, PT_EINVAL, "pt_create: rank %u outside world %u", cfg->rank, world);
-	if (cfg->flags & PT_FLAG_SHADOW_ANYHIT) return fail(nullptr, PT_EINVAL, "pt_create: PT_FLAG_SHADOW_ANYHIT is not built yet");
 
 	int ndev = 0;
 	hipError_t e = hipGetDeviceCount(&ndev);

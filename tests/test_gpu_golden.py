@@ -31,7 +31,7 @@ def test_frame_golden(pt, golden, name):
     sc = _scene(pt, name)
     assert sc.hash() == int(g[f"{name}_hash"][0])
     env = golden_env() if name.endswith("_env") else None
-    c = pt.PathTracer(64, 64, flags=pt.PT_FLAG_TRACE_DEAD_PATHS | pt.PT_FLAG_COUNT_TRAVERSAL)
+    c = pt.PathTracer(64, 64, flags=pt.PT_FLAG_TRACE_DEAD_PATHS | pt.PT_FLAG_COUNT_TRAVERSAL | pt.PT_FLAG_SHADOW_FULL_TRAVERSAL)
     try:
         c.upload_scene(sc, env_rgb8=env)
         c.set_camera(pt.default_camera())

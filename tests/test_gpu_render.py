@@ -79,3 +79,43 @@ def test_batch_size_does_not_change_the_image(pt):
     for im in imgs[1:]:
         assert np.array_equal(imgs[0].view(np.uint32), im.view(np.uint32))
     assert not np.array_equal(more, imgs[0])
+
+
+def _render(pt, scene, w, h, n, flags):
+    c = pt.PathTracer(w, h, flags=flags)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        c.render(0, pt.frame_seeds(0, n), 5)
+        return c.read_framebuffer(), c.counters()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("name", ["cornell_spheres", "bunny"])
+def test_shadow_early_out_is_exact(pt, name):
+    """Default shadow traversal stops at the first hit that already decides the reference's compare: same pixels, same
+    ray counts, less traversal work than going on to the closest hit."""
+    scene = pt.Scene.cornell(spheres=True) if name == "cornell_spheres" else pt.Scene.bunny(freq=16, target_tris=0, spheres=True)
+    full, cf = _render(pt, scene, 96, 64, 4, pt.PT_FLAG_COUNT_TRAVERSAL | pt.PT_FLAG_SHADOW_FULL_TRAVERSAL)
+    fast, ce = _render(pt, scene, 96, 64, 4, pt.PT_FLAG_COUNT_TRAVERSAL)
+    assert np.array_equal(full.view(np.uint32), fast.view(np.uint32))
+    for k in ("rays_primary", "rays_shadow", "rays_bounce"):
+        assert cf[k] == ce[k]
+    assert ce["node_steps"] < cf["node_steps"] and ce["tri_tests"] <= cf["tri_tests"]
+    print(name, "node steps", cf["node_steps"], "->", ce["node_steps"], "tri tests", cf["tri_tests"], "->", ce["tri_tests"])
+
+
+def test_anyhit_mode_is_close(pt):
+    """PT_FLAG_SHADOW_ANYHIT drops the one-sided quirk of the shadow compare: not bit-exact, but the same picture.
+    Stated tolerance: image RMSE <= 3 % of the mean radiance at 32 spp, mean radiance within 2 %."""
+    scene = pt.Scene.bunny(freq=16, target_tris=0)
+    ref, cr = _render(pt, scene, 96, 64, 32, pt.PT_FLAG_COUNT_TRAVERSAL)
+    any_, ca = _render(pt, scene, 96, 64, 32, pt.PT_FLAG_COUNT_TRAVERSAL | pt.PT_FLAG_SHADOW_ANYHIT)
+    mean = float(ref[..., :3].mean())
+    rmse = float(np.sqrt(np.mean((ref[..., :3] - any_[..., :3]) ** 2)))
+    print("anyhit: mean", mean, float(any_[..., :3].mean()), "rmse", rmse, "steps", cr["node_steps"], "->", ca["node_steps"])
+    assert abs(float(any_[..., :3].mean()) - mean) <= 0.02 * mean
+    assert rmse <= 0.03 * mean
+    assert ca["node_steps"] < cr["node_steps"]
+    assert float(any_[..., :3].mean()) <= mean * 1.0001  # any-hit can only remove light the quirk let through
