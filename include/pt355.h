@@ -5,7 +5,7 @@
  * the reference interface it stands in for (paths relative to the reference
  * repository root).  Plain C types only; no exceptions cross this boundary; all
  * functions return 0 on success and a PT_E* code otherwise (pt_last_error gives
- * the text).  One pt_ctx per host thread; one HIP stream per context.
+ * the text).  One pt_ctx per host thread; a context owns its HIP streams.
  *
  * Buffer layouts are the reference's, byte for byte:
  *   sphere    32 B  src/scene/sphere.hpp:7-15      shaders/framebuffer.comp:54-58
@@ -59,7 +59,9 @@ typedef struct pt_config {
 	uint32_t rank, world;  /* this context's share; world = 0 or 1 means the whole image */
 	uint32_t max_batch;    /* frames pt_render traces together (1..16); 0 = default (8, less for very large images).
 	                          Results do not depend on it: samples are blended into the image in frame order. */
-	uint32_t reserved[8];
+	uint32_t pipelines;    /* independent frame pipelines (streams + queues) batches alternate between (1..4); 0 = default (1).
+	                          Results do not depend on it either. */
+	uint32_t reserved[7];
 } pt_config;
 
 /* Replaces: the six PushDataToSSBO calls, bindings 0..5 in call order (src/main.cpp:57-63,

@@ -30,7 +30,7 @@ class PtError(RuntimeError):
 
 class pt_config(ctypes.Structure):
     _fields_ = [("width", c_uint32), ("height", c_uint32), ("device", c_int32), ("flags", c_uint32),
-                ("partition", c_uint32), ("rank", c_uint32), ("world", c_uint32), ("max_batch", c_uint32), ("reserved", c_uint32 * 8)]
+                ("partition", c_uint32), ("rank", c_uint32), ("world", c_uint32), ("max_batch", c_uint32), ("pipelines", c_uint32), ("reserved", c_uint32 * 7)]
 
 
 class pt_scene_desc(ctypes.Structure):
@@ -232,10 +232,10 @@ class PathTracer:
     """One pt_ctx: the replacement for the reference's GL upload + glDispatchCompute sequence."""
 
     def __init__(self, width: int, height: int, device: int = 0, flags: int = 0, partition: int = PT_PARTITION_FULL,
-                 rank: int = 0, world: int = 1, max_batch: int = 0):
+                 rank: int = 0, world: int = 1, max_batch: int = 0, pipelines: int = 0):
         L = lib()
         cfg = pt_config(width=width, height=height, device=device, flags=flags, partition=partition, rank=rank, world=world,
-                        max_batch=max_batch)
+                        max_batch=max_batch, pipelines=pipelines)
         h = c_void_p()
         rc = L.pt_create(byref(cfg), byref(h))
         if rc != 0:

@@ -1,5 +1,9 @@
 // libpt355.so -- context management and the C ABI of include/pt355.h over the gfx950 kernels.
-// One context = one device, one stream, scene copies in HBM, two ping-pong path queues.
+// One context = one device, scene copies in HBM, one RGBA32F image, and 1..4 frame pipelines: each pipeline has its
+// own stream, two ping-pong path queues, control block and sample store, and renders every n-th batch of frames.
+// Batches are blended into the image in frame order (an event chain between the pipelines' resolve kernels).
+// Default is ONE pipeline: with two, one pipeline's shading does run beside the other's traversal, but both stretch
+// (they queue on the same vector-memory pipeline) and the frame time does not improve.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -18,11 +22,24 @@ thread_local std::string g_create_error;
 
 struct EventPair { hipEvent_t a, b; int kind; };
 
+#define PT_MAX_PIPES 4
+
+struct Pipe {
+	hipStream_t stream = nullptr;
+	void *queue_alloc = nullptr;
+	PathQ q[2];
+	DevCtl *ctl = nullptr;
+	uint32_t *spill = nullptr;
+	float4 *sample = nullptr;
+	hipEvent_t resolved = nullptr; // recorded behind this pipeline's latest k_resolve
+	std::vector<EventPair> pending;
+};
+
 } // namespace
 
 struct pt_ctx {
 	pt_config cfg;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr; // = pipe[0].stream: uploads, image copies, pack/unpack, the stand-alone trace entry
 	std::string err;
 	int n_cu = 0;
 	int trace_grid = 0;
@@ -39,15 +56,14 @@ struct pt_ctx {
 	uint32_t n_paths = 0;   // paths per frame = pixels this rank owns
 	uint32_t max_batch = 1; // frames traced together (pt_config.max_batch)
 	uint32_t stride = 0, cap = 0, blocks_per_region = 0;
-	float4 *sample = nullptr;
-	void *queue_alloc = nullptr;
-	PathQ q[2];
-	DevCtl *ctl = nullptr;
-	uint32_t *spill = nullptr;
+	Pipe pipe[PT_MAX_PIPES];
+	uint32_t n_pipes = 1, next_pipe = 0;
+	int last_resolved = -1;  // pipeline whose k_resolve was enqueued last (the next one waits for it)
+	bool in_flight = false;  // renders enqueued since the last join
 	float *fb = nullptr;
 
 	// timing
-	std::vector<EventPair> pending, free_events;
+	std::vector<EventPair> free_events;
 	double ms_trace = 0, ms_shade = 0;
 	uint64_t trace_launches = 0, frames = 0;
 };
@@ -88,28 +104,40 @@ uint32_t host_path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_
 	return ((tile / tiles_x) * 8u + (in >> 3)) * width + (tile % tiles_x) * 8u + (in & 7u);
 }
 
-void begin_timed(pt_ctx *c, int kind)
+void begin_timed(pt_ctx *c, Pipe &pp, int kind)
 {
 	EventPair ev;
 	if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
 	else { hipEventCreate(&ev.a); hipEventCreate(&ev.b); }
 	ev.kind = kind;
-	hipEventRecord(ev.a, c->stream);
-	c->pending.push_back(ev);
+	hipEventRecord(ev.a, pp.stream);
+	pp.pending.push_back(ev);
 }
-void end_timed(pt_ctx *c) { hipEventRecord(c->pending.back().b, c->stream); }
+void end_timed(Pipe &pp) { hipEventRecord(pp.pending.back().b, pp.stream); }
 
+// every pipeline idle: the image and the counters are complete
+int join(pt_ctx *c)
+{
+	for (uint32_t i = 0; i < c->n_pipes; i++)
+		if (c->pipe[i].stream) HIP_TRY(c, hipStreamSynchronize(c->pipe[i].stream));
+	c->in_flight = false;
+	return PT_OK;
+}
+
+// Kernel times are summed per kind; with two pipelines their kernels overlap, so the sums can exceed wall time.
 int drain_events(pt_ctx *c)
 {
-	if (c->pending.empty()) return PT_OK;
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	for (EventPair &ev : c->pending) {
-		float ms = 0;
-		hipEventElapsedTime(&ms, ev.a, ev.b);
-		if (ev.kind == 0) c->ms_trace += ms; else c->ms_shade += ms;
-		c->free_events.push_back(ev);
+	int rc = join(c);
+	if (rc) return rc;
+	for (uint32_t i = 0; i < c->n_pipes; i++) {
+		for (EventPair &ev : c->pipe[i].pending) {
+			float ms = 0;
+			hipEventElapsedTime(&ms, ev.a, ev.b);
+			if (ev.kind == 0) c->ms_trace += ms; else c->ms_shade += ms;
+			c->free_events.push_back(ev);
+		}
+		c->pipe[i].pending.clear();
 	}
-	c->pending.clear();
 	return PT_OK;
 }
 
@@ -145,37 +173,37 @@ void carve_queue(PathQ &q, char *&p, uint32_t stride)
 }
 const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
 
-int launch_trace(pt_ctx *c, const TraceArgs &ta)
+int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta)
 {
-	begin_timed(c, 0);
+	begin_timed(c, pp, 0);
 	if (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL)
-		hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+		hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
 	else
-		hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
-	end_timed(c);
+		hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
+	end_timed(pp);
 	c->trace_launches++;
 	HIP_TRY(c, hipGetLastError());
 	return PT_OK;
 }
 
-TraceArgs queue_trace_args(pt_ctx *c, uint32_t qi, bool with_shadow)
+TraceArgs queue_trace_args(pt_ctx *c, Pipe &pp, uint32_t qi, bool with_shadow)
 {
 	TraceArgs ta;
 	memset(&ta, 0, sizeof ta);
 	ta.sc = c->sc;
-	ta.seg[0].ray = c->q[qi].ray; ta.seg[0].hit = c->q[qi].hit; ta.seg[0].valid = nullptr;
-	ta.seg[1].ray = c->q[qi].sray; ta.seg[1].hit = c->q[qi].shit; ta.seg[1].valid = c->q[qi].meta;
-	ta.seg[1].target = c->q[qi].nee + 5 * (size_t) c->stride;
+	ta.seg[0].ray = pp.q[qi].ray; ta.seg[0].hit = pp.q[qi].hit; ta.seg[0].valid = nullptr;
+	ta.seg[1].ray = pp.q[qi].sray; ta.seg[1].hit = pp.q[qi].shit; ta.seg[1].valid = pp.q[qi].meta;
+	ta.seg[1].target = pp.q[qi].nee + 5 * (size_t) c->stride;
 	ta.shadow_mode = (c->cfg.flags & PT_FLAG_SHADOW_ANYHIT) ? PT_SHADOW_ANYHIT
 	               : (c->cfg.flags & PT_FLAG_SHADOW_FULL_TRAVERSAL) ? PT_SHADOW_FULL : PT_SHADOW_EXACT;
 	ta.stride = c->stride;
 	ta.cap = c->cap;
-	ta.count_ptr = c->ctl->qcount[qi];
+	ta.count_ptr = pp.ctl->qcount[qi];
 	ta.n_segs = with_shadow ? 2 : 1;
 	ta.refill_threshold = c->refill_threshold;
-	ta.ctl = c->ctl;
-	ta.zero_on_entry = c->ctl->qcount[qi ^ 1u];
-	ta.spill = c->spill;
+	ta.ctl = pp.ctl;
+	ta.zero_on_entry = pp.ctl->qcount[qi ^ 1u];
+	ta.spill = pp.spill;
 	return ta;
 }
 
@@ -219,7 +247,14 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	hipDeviceProp_t prop;
 	CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
 	c->n_cu = prop.multiProcessorCount;
-	CREATE_TRY(hipStreamCreate(&c->stream));
+	c->n_pipes = cfg->pipelines ? cfg->pipelines : 1u; // 2..4 measured no faster: DESIGN.md "What was tried"
+	if (const char *e = getenv("PT355_PIPES")) { int v = atoi(e); if (v >= 1) c->n_pipes = (uint32_t) v; }
+	if (c->n_pipes > PT_MAX_PIPES) c->n_pipes = PT_MAX_PIPES;
+	for (uint32_t i = 0; i < c->n_pipes; i++) {
+		CREATE_TRY(hipStreamCreate(&c->pipe[i].stream));
+		CREATE_TRY(hipEventCreateWithFlags(&c->pipe[i].resolved, hipEventDisableTiming));
+	}
+	c->stream = c->pipe[0].stream;
 
 	int blocks_per_cu = 0;
 	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false>, PT_TRACE_BLOCK, 0));
@@ -245,19 +280,22 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 		c->stride = c->cap * PT_SHARDS;
 	}
 	const size_t qbytes = (size_t) kQueueCols * c->stride * 4;
-	CREATE_TRY(hipMalloc(&c->queue_alloc, 2 * qbytes));
-	CREATE_TRY(hipMemsetAsync(c->queue_alloc, 0, 2 * qbytes, c->stream));
-	char *p = (char *) c->queue_alloc;
-	carve_queue(c->q[0], p, c->stride);
-	carve_queue(c->q[1], p, c->stride);
-	CREATE_TRY(hipMalloc((void **) &c->ctl, sizeof(DevCtl)));
-	CREATE_TRY(hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
-	CREATE_TRY(hipMalloc((void **) &c->spill, (size_t) c->trace_grid * PT_TRACE_WAVES * PT_SPILL_STACK * 64 * 4));
-	CREATE_TRY(hipMalloc((void **) &c->sample, ((size_t) c->max_batch * c->n_paths + 1) * 16));
+	for (uint32_t i = 0; i < c->n_pipes; i++) {
+		Pipe &pp = c->pipe[i];
+		CREATE_TRY(hipMalloc(&pp.queue_alloc, 2 * qbytes));
+		CREATE_TRY(hipMemsetAsync(pp.queue_alloc, 0, 2 * qbytes, pp.stream));
+		char *p = (char *) pp.queue_alloc;
+		carve_queue(pp.q[0], p, c->stride);
+		carve_queue(pp.q[1], p, c->stride);
+		CREATE_TRY(hipMalloc((void **) &pp.ctl, sizeof(DevCtl)));
+		CREATE_TRY(hipMemsetAsync(pp.ctl, 0, sizeof(DevCtl), pp.stream));
+		CREATE_TRY(hipMalloc((void **) &pp.spill, (size_t) c->trace_grid * PT_TRACE_WAVES * PT_SPILL_STACK * 64 * 4));
+		CREATE_TRY(hipMalloc((void **) &pp.sample, ((size_t) c->max_batch * c->n_paths + 1) * 16));
+	}
 	const size_t fb_bytes = (size_t) cfg->width * cfg->height * 16;
 	CREATE_TRY(hipMalloc((void **) &c->fb, fb_bytes));
 	CREATE_TRY(hipMemsetAsync(c->fb, 0, fb_bytes, c->stream));
-	CREATE_TRY(hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i < c->n_pipes; i++) CREATE_TRY(hipStreamSynchronize(c->pipe[i].stream));
 #undef CREATE_TRY
 	*out = c;
 	return PT_OK;
@@ -267,16 +305,20 @@ int pt_destroy(pt_ctx *c)
 {
 	if (!c) return PT_OK;
 	hipSetDevice(c->cfg.device);
-	if (c->stream) hipStreamSynchronize(c->stream);
-	for (EventPair &ev : c->pending) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+	for (uint32_t i = 0; i < PT_MAX_PIPES; i++) {
+		Pipe &pp = c->pipe[i];
+		if (pp.stream) hipStreamSynchronize(pp.stream);
+		for (EventPair &ev : pp.pending) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
+		if (pp.queue_alloc) hipFree(pp.queue_alloc);
+		if (pp.ctl) hipFree(pp.ctl);
+		if (pp.spill) hipFree(pp.spill);
+		if (pp.sample) hipFree(pp.sample);
+		if (pp.resolved) hipEventDestroy(pp.resolved);
+	}
 	for (EventPair &ev : c->free_events) { hipEventDestroy(ev.a); hipEventDestroy(ev.b); }
 	free_scene(c);
-	if (c->queue_alloc) hipFree(c->queue_alloc);
-	if (c->ctl) hipFree(c->ctl);
-	if (c->spill) hipFree(c->spill);
 	if (c->fb) hipFree(c->fb);
-	if (c->sample) hipFree(c->sample);
-	if (c->stream) hipStreamDestroy(c->stream);
+	for (uint32_t i = 0; i < PT_MAX_PIPES; i++) if (c->pipe[i].stream) hipStreamDestroy(c->pipe[i].stream);
 	delete c;
 	return PT_OK;
 }
@@ -315,7 +357,7 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 		for (uint32_t i = 0; i < s->n_light_spheres; i++)
 			if (s->light_spheres[i] >= s->n_spheres) return fail(c, PT_EINVAL, "pt_upload_scene: light sphere index out of range");
 	}
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	{ int rc = join(c); if (rc) return rc; }
 	free_scene(c);
 	DevScene d;
 	memset(&d, 0, sizeof d);
@@ -362,11 +404,16 @@ int pt_set_camera(pt_ctx *c, const float cam[12])
 	return PT_OK;
 }
 
-// n_batch consecutive frames through one set of launches: raygen, (trace, shade) x (bounces + 1), resolve
+// n_batch consecutive frames through one set of launches on the next pipeline:
+// raygen, (trace, shade) x (bounces + 1), resolve
 static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const uint32_t *seeds, uint32_t bounces)
 {
 	if (c->n_paths == 0) { c->frames += n_batch; return PT_OK; }
-	if (c->pending.size() > 4096) { int rc = drain_events(c); if (rc) return rc; }
+	const uint32_t pi = c->next_pipe;
+	Pipe &pp = c->pipe[pi];
+	c->next_pipe = (pi + 1u) % c->n_pipes;
+	if (pp.pending.size() > 4096) { int rc = drain_events(c); if (rc) return rc; }
+	c->in_flight = true;
 
 	ShadeArgs sa;
 	memset(&sa, 0, sizeof sa);
@@ -374,12 +421,12 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	sa.stride = c->stride;
 	sa.cap = c->cap;
 	sa.blocks_per_region = c->blocks_per_region;
-	sa.ctl = c->ctl;
+	sa.ctl = pp.ctl;
 	memcpy(sa.cam, c->cam, sizeof sa.cam);
 	sa.width = c->cfg.width; sa.height = c->cfg.height;
 	sa.bounces = bounces;
 	sa.flags = c->cfg.flags;
-	sa.sample = c->sample;
+	sa.sample = pp.sample;
 	sa.fb = c->fb;
 	sa.n_batch = n_batch; sa.first_frame = first_frame; sa.n_paths_frame = c->n_paths;
 	const uint32_t n_total = n_batch * c->n_paths;
@@ -391,25 +438,38 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	// own size are empty and their blocks return after one load, so the grid simply covers every slot
 	const dim3 sgrid(c->stride / PT_SHADE_BLOCK);
 
-	sa.out = c->q[0];
-	begin_timed(c, 1);
-	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, c->stream, sa);
-	end_timed(c);
+	sa.out = pp.q[0];
+	begin_timed(c, pp, 1);
+	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
+	end_timed(pp);
 	uint32_t qi = 0;
 	for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
-		int rc = launch_trace(c, queue_trace_args(c, qi, stage > 0));
+		int rc = launch_trace(c, pp, queue_trace_args(c, pp, qi, stage > 0));
 		if (rc) return rc;
-		sa.in = c->q[qi]; sa.out = c->q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
-		begin_timed(c, 1);
-		hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, c->stream, sa);
-		end_timed(c);
+		sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
+		begin_timed(c, pp, 1);
+		hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, pp.stream, sa);
+		end_timed(pp);
 		qi ^= 1u;
 	}
-	begin_timed(c, 1);
-	hipLaunchKernelGGL(k_resolve, dim3((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, c->stream, sa);
-	end_timed(c);
+	// the running mean is order-dependent: this batch is blended after the previous one, whichever pipeline ran it
+	if (c->last_resolved >= 0 && (uint32_t) c->last_resolved != pi)
+		HIP_TRY(c, hipStreamWaitEvent(pp.stream, c->pipe[c->last_resolved].resolved, 0));
+	begin_timed(c, pp, 1);
+	hipLaunchKernelGGL(k_resolve, dim3((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
+	end_timed(pp);
+	HIP_TRY(c, hipEventRecord(pp.resolved, pp.stream));
+	c->last_resolved = (int) pi;
 	HIP_TRY(c, hipGetLastError());
 	c->frames += n_batch;
+	return PT_OK;
+}
+
+// image written on pipeline 0's stream outside a render (clear, unpack): later blends must come after it
+static int image_touched(pt_ctx *c)
+{
+	HIP_TRY(c, hipEventRecord(c->pipe[0].resolved, c->stream));
+	c->last_resolved = 0;
 	return PT_OK;
 }
 
@@ -439,8 +499,7 @@ int pt_sync(pt_ctx *c)
 {
 	if (!c) return PT_EINVAL;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
-	return PT_OK;
+	return join(c);
 }
 
 int pt_read_framebuffer(pt_ctx *c, float *rgba, size_t n_floats)
@@ -449,6 +508,7 @@ int pt_read_framebuffer(pt_ctx *c, float *rgba, size_t n_floats)
 	const size_t need = (size_t) c->cfg.width * c->cfg.height * 4;
 	if (n_floats != need) return fail(c, PT_EINVAL, "pt_read_framebuffer: expected %zu floats, got %zu", need, n_floats);
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	{ int rc = join(c); if (rc) return rc; }
 	HIP_TRY(c, hipMemcpyAsync(rgba, c->fb, need * 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	return PT_OK;
@@ -458,8 +518,9 @@ int pt_clear_framebuffer(pt_ctx *c)
 {
 	if (!c) return PT_EINVAL;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	{ int rc = join(c); if (rc) return rc; }
 	HIP_TRY(c, hipMemsetAsync(c->fb, 0, (size_t) c->cfg.width * c->cfg.height * 16, c->stream));
-	return PT_OK;
+	return image_touched(c);
 }
 
 int pt_framebuffer_device(pt_ctx *c, void **dev_ptr)
@@ -475,7 +536,9 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	if (!c->have_scene) return fail(c, PT_ESTATE, "pt_trace_closest: upload a scene first");
 	if (n == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	HIP_TRY(c, hipMemsetAsync(c->ctl->shard, 0, sizeof(c->ctl->shard), c->stream));
+	if (c->in_flight) { int rc = join(c); if (rc) return rc; } // borrows pipeline 0's control block and spill tail
+	Pipe &pp = c->pipe[0];
+	HIP_TRY(c, hipMemsetAsync(pp.ctl->shard, 0, sizeof(pp.ctl->shard), c->stream));
 	TraceArgs ta;
 	memset(&ta, 0, sizeof ta);
 	ta.sc = c->sc;
@@ -483,9 +546,9 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	ta.stride = n; ta.n_fixed = n; ta.n_segs = 1;
 	ta.cap = (((n + 63u) / 64u + PT_SHARDS - 1) / PT_SHARDS) * 64u; // whole 64-ray units per region
 	ta.refill_threshold = c->refill_threshold;
-	ta.ctl = c->ctl;
-	ta.spill = c->spill;
-	return launch_trace(c, ta);
+	ta.ctl = pp.ctl;
+	ta.spill = pp.spill;
+	return launch_trace(c, pp, ta);
 }
 
 int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv)
@@ -533,17 +596,19 @@ int pt_get_counters(pt_ctx *c, pt_counters *out)
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	int rc = drain_events(c);
 	if (rc) return rc;
-	DevCtl h;
-	HIP_TRY(c, hipMemcpyAsync(&h, c->ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	memset(out, 0, sizeof *out);
 	out->frames = c->frames;
-	out->paths = h.paths; out->rays_primary = h.rays_primary;
-	for (uint32_t r = 0; r < PT_SHARDS; r++) {
-		out->rays_shadow += h.rays_shadow[r * (PT_SHARD_STRIDE / 2)];
-		out->rays_bounce += h.rays_bounce[r * (PT_SHARD_STRIDE / 2)];
+	for (uint32_t i = 0; i < c->n_pipes; i++) {
+		static thread_local DevCtl h;
+		HIP_TRY(c, hipMemcpyAsync(&h, c->pipe[i].ctl, sizeof h, hipMemcpyDeviceToHost, c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		out->paths += h.paths; out->rays_primary += h.rays_primary;
+		for (uint32_t r = 0; r < PT_SHARDS; r++) {
+			out->rays_shadow += h.rays_shadow[r * (PT_SHARD_STRIDE / 2)];
+			out->rays_bounce += h.rays_bounce[r * (PT_SHARD_STRIDE / 2)];
+		}
+		out->node_steps += h.node_steps; out->tri_tests += h.tri_tests; out->stack_spills += h.stack_spills;
 	}
-	out->node_steps = h.node_steps; out->tri_tests = h.tri_tests; out->stack_spills = h.stack_spills;
 	out->ms_trace = c->ms_trace; out->ms_shade = c->ms_shade; out->trace_launches = c->trace_launches;
 	return PT_OK;
 }
@@ -554,7 +619,7 @@ int pt_reset_counters(pt_ctx *c)
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	int rc = drain_events(c);
 	if (rc) return rc;
-	HIP_TRY(c, hipMemsetAsync(c->ctl, 0, sizeof(DevCtl), c->stream));
+	for (uint32_t i = 0; i < c->n_pipes; i++) HIP_TRY(c, hipMemsetAsync(c->pipe[i].ctl, 0, sizeof(DevCtl), c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->ms_trace = c->ms_shade = 0; c->trace_launches = 0; c->frames = 0;
 	return PT_OK;
@@ -581,6 +646,7 @@ int pt_pack_owned(pt_ctx *c, void *dst_dev)
 	if (!c || !dst_dev) return PT_EINVAL;
 	if (c->n_paths == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	if (c->in_flight) { int rc = join(c); if (rc) return rc; }
 	hipLaunchKernelGGL(k_pack_owned, dim3((c->n_paths + 255) / 256), dim3(256), 0, c->stream, (const float4 *) c->fb, (float4 *) dst_dev,
 	                   c->n_paths, c->cfg.width, c->cfg.partition, c->cfg.rank, c->cfg.world);
 	HIP_TRY(c, hipGetLastError());
@@ -595,24 +661,26 @@ int pt_unpack_from(pt_ctx *c, const void *src_dev, uint32_t from_rank, uint32_t 
 	const uint32_t n = own_tiles(c->cfg.width, c->cfg.height, PT_PARTITION_TILES, from_rank, world) * 64u;
 	if (n == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	if (c->in_flight) { int rc = join(c); if (rc) return rc; }
 	hipLaunchKernelGGL(k_unpack_from, dim3((n + 255) / 256), dim3(256), 0, c->stream, (float4 *) c->fb, (const float4 *) src_dev, n,
 	                   c->cfg.width, (uint32_t) PT_PARTITION_TILES, from_rank, world);
 	HIP_TRY(c, hipGetLastError());
-	return PT_OK;
+	return image_touched(c);
 }
 
 int pt_debug_read_queue(pt_ctx *c, uint32_t queue, uint32_t field, void *out, size_t n_words, uint32_t *stride, uint32_t *count)
 {
 	if (!c || queue > 1 || field > 10 || !out) return PT_EINVAL;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	const PathQ &q = c->q[queue];
+	{ int rc = join(c); if (rc) return rc; }
+	const PathQ &q = c->pipe[0].q[queue];
 	const void *base[11] = {q.pix, q.rng, q.meta, q.thr, q.col, q.ray, q.sray, q.nee, q.bs, q.hit, q.shit};
 	const uint32_t cols[11] = {1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4};
 	const size_t need = (size_t) cols[field] * c->stride;
 	if (n_words != need) return fail(c, PT_EINVAL, "pt_debug_read_queue: field %u needs %zu words", field, need);
 	HIP_TRY(c, hipMemcpyAsync(out, base[field], need * 4, hipMemcpyDeviceToHost, c->stream));
 	static uint32_t qc[PT_SHARDS * PT_SHARD_STRIDE];
-	HIP_TRY(c, hipMemcpyAsync(qc, c->ctl->qcount[queue], sizeof qc, hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(qc, c->pipe[0].ctl->qcount[queue], sizeof qc, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if (stride) *stride = c->stride;
 	if (count) { *count = 0; for (uint32_t r = 0; r < PT_SHARDS; r++) *count += qc[r * PT_SHARD_STRIDE]; }

@@ -56,8 +56,8 @@ def test_batch_size_does_not_change_the_image(pt):
     scene = pt.Scene.bunny(freq=10, target_tris=0, spheres=True)
     cam, seeds = pt.default_camera(), pt.frame_seeds(0, 7)
     imgs = []
-    for mb in (1, 3, 8, 16):
-        c = pt.PathTracer(72, 40, max_batch=mb)
+    for mb, pipes in ((1, 1), (3, 2), (8, 1), (16, 2), (2, 4)):
+        c = pt.PathTracer(72, 40, max_batch=mb, pipelines=pipes)
         try:
             c.upload_scene(scene)
             c.set_camera(cam)
