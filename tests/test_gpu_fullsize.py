@@ -1,0 +1,128 @@
+"""BASELINE.json's configurations at (or near) their full sizes: HIP path vs the oracle where the oracle finishes in
+seconds, and size-independent properties (batch / pipeline invariance, tile and sample partitions) beyond that."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1920, 1080
+
+
+def _gpu(pt, scene, w, h, seeds, first=0, flags=0, **kw):
+    c = pt.PathTracer(w, h, flags=flags, **kw)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        c.render(first, seeds, 5)
+        return c.read_framebuffer(), c.counters()
+    finally:
+        c.close()
+
+
+def _vs_oracle(pt, ol, scene, w, h, n):
+    seeds = pt.frame_seeds(0, n)
+    img, cnt = _gpu(pt, scene, w, h, seeds, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+    ref, ocnt = ol.render(ol.scene_from_desc(scene.desc()), pt.default_camera(), w, h, seeds, threads=16)
+    bad = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+    assert bad == 0, f"{bad} of {w * h} pixels differ"
+    for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce"):
+        assert cnt[k] == ocnt[k], k
+    assert np.isfinite(img).all()
+    return cnt, ocnt
+
+
+def test_config1_bunny_oren_nayar_1080p(pt, ol):
+    """configs[1]: bunny-class mesh (69,463 triangles after the shell), Lambert walls + Oren-Nayar mesh, 1920x1080."""
+    scene = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
+    cnt, ocnt = _vs_oracle(pt, ol, scene, W, H, 2)
+    assert cnt["stack_spills"] == 0 and ocnt["max_stack"] <= 16
+
+
+def test_config2_bunny_ggx_gold_1080p(pt, ol):
+    """configs[2]: the same mesh as GGX metallic gold, GGX importance sampling + NEE, plus the four gold spheres."""
+    scene = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_SPECULAR_METAL, roughness=0.2, spheres=True)
+    _vs_oracle(pt, ol, scene, W, H, 2)
+
+
+def test_config3_262k_triangles_1080p(pt, ol):
+    """configs[3] stand-in: ~262k triangles (Sponza-class count; the real asset is not available offline)."""
+    scene = pt.Scene.bunny(freq=115, target_tris=262144, seed=3, material=pt.MAT_OREN_NAYAR, roughness=0.175, spheres=True)
+    assert scene.desc().n_tris > 262000
+    _vs_oracle(pt, ol, scene, W, H, 1)
+
+
+def test_config4_million_triangles(pt, ol):
+    """configs[4] stand-in: 2*10^6 triangles at 3840x2160 -- primitive indices far beyond the hit record's u16 object
+    index (the wrapped index feeds the MIS light pdf) and a BVH of ~3 M float-encoded node indices."""
+    scene = pt.Scene.soup(2000000, seed=21, size=0.015)
+    assert scene.desc().n_nodes > 2000000
+    _vs_oracle(pt, ol, scene, 3840, 2160, 1)
+
+
+def test_batches_and_pipelines_at_full_size(pt):
+    scene = pt.Scene.bunny(freq=59, target_tris=69451, seed=1)
+    seeds = pt.frame_seeds(0, 9)
+    a, ca = _gpu(pt, scene, W, H, seeds, max_batch=1)
+    b, cb = _gpu(pt, scene, W, H, seeds, max_batch=8)
+    c, cc = _gpu(pt, scene, W, H, seeds, max_batch=4, pipelines=2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce"):
+        assert ca[k] == cb[k] == cc[k]
+
+
+def test_tile_partition_is_bit_identical(pt):
+    """SURVEY 8e 'virtual devices': three tile-partition contexts on one GPU, gathered through pt_pack_owned /
+    pt_unpack_from, reproduce the single-context image bit for bit."""
+    import torch
+    scene = pt.Scene.bunny(freq=20, target_tris=0, spheres=True)
+    w, h, seeds = 640, 360, pt.frame_seeds(0, 3)
+    whole, _ = _gpu(pt, scene, w, h, seeds)
+    world = 3
+    root = pt.PathTracer(w, h)  # rank 0's full image, receives the tiles
+    try:
+        total_rays = 0
+        for r in range(world):
+            c = pt.PathTracer(w, h, partition=pt.PT_PARTITION_TILES, rank=r, world=world)
+            try:
+                c.upload_scene(scene)
+                c.set_camera(pt.default_camera())
+                c.render(0, seeds, 5)
+                n = pt.partition_pixels(w, h, pt.PT_PARTITION_TILES, r, world).size
+                buf = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                c.pack_owned(buf.data_ptr())
+                c.sync()
+                cnt = c.counters()
+                total_rays += cnt["rays_primary"]
+                assert cnt["paths"] == n * 3
+            finally:
+                c.close()
+            root.unpack_from(buf.data_ptr(), r, world)
+            root.sync()
+        got = root.read_framebuffer()
+    finally:
+        root.close()
+    assert total_rays == w * h * 3
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
+def test_sample_partition_matches_sequential(pt):
+    """Frames dealt round-robin to two 'ranks' with local blend weights, combined as sum_r (n_r/N) mean_r: equal to the
+    sequential running mean up to summation order (tolerance 2e-6 relative, floor 1e-3 absolute radiance)."""
+    from pathtracer_amd import multigpu as mg
+    scene = pt.Scene.cornell(spheres=True)
+    w, h, n = 256, 256, 10
+    seeds = pt.frame_seeds(0, n)
+    seq, _ = _gpu(pt, scene, w, h, seeds)
+    acc = np.zeros((h, w, 4), np.float64)
+    for r in range(2):
+        c = pt.PathTracer(w, h)
+        try:
+            c.upload_scene(scene)
+            c.set_camera(pt.default_camera())
+            k = mg.render_sample_share(c, seeds, 0, n, r, 2)
+            acc += c.read_framebuffer().astype(np.float32) * np.float32(k / n)
+        finally:
+            c.close()
+    err = np.abs(acc[..., :3] - seq[..., :3]) / np.maximum(np.abs(seq[..., :3]), 1e-3)
+    assert err.max() < 2e-6, err.max()
