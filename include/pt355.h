@@ -57,7 +57,7 @@ typedef struct pt_config {
 	uint32_t flags;
 	uint32_t partition;    /* PT_PARTITION_* */
 	uint32_t rank, world;  /* this context's share; world = 0 or 1 means the whole image */
-	uint32_t max_batch;    /* frames pt_render traces together (1..16); 0 = default (8, less for very large images).
+	uint32_t max_batch;    /* frames pt_render traces together (1..32); 0 = default (16, less for very large images).
 	                          Results do not depend on it: samples are blended into the image in frame order. */
 	uint32_t pipelines;    /* independent frame pipelines (streams + queues) batches alternate between (1..4); 0 = default (1).
 	                          Results do not depend on it either. */
@@ -131,6 +131,10 @@ int pt_trace_closest(pt_ctx *ctx, const float *ro, const float *rd, uint32_t n,
 /* Same kernel on rays already resident in HBM: ray6 = structure-of-arrays ro.x[n] ro.y[n] ro.z[n] rd.x[n] rd.y[n]
  * rd.z[n]; hit4 = one 16-byte record per ray, 16-byte aligned: {prim u32, t_h | kind<<16, u f32, v f32}.  Asynchronous. */
 int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
+
+/* What pt_create settled on (no reference counterpart): info[0] frames per launch set, [1] pipelines, [2] queue stride
+ * (slots), [3] slots per queue region, [4] paths per frame on this rank, [5] k_trace grid (blocks), [6..7] zero. */
+int pt_get_info(const pt_ctx *ctx, uint32_t info[8]);
 
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);
 int pt_reset_counters(pt_ctx *ctx);

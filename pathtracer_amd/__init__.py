@@ -68,6 +68,7 @@ EXPORTS = {
     "pt_framebuffer_device": (c_int, [c_void_p, POINTER(c_void_p)]),
     "pt_trace_closest": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pt_trace_closest_device": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
+    "pt_get_info": (c_int, [c_void_p, c_void_p]),
     "pt_get_counters": (c_int, [c_void_p, POINTER(pt_counters)]),
     "pt_reset_counters": (c_int, [c_void_p]),
     "pt_partition_count": (c_uint32, [c_uint32, c_uint32, c_uint32, c_uint32, c_uint32]),
@@ -243,7 +244,9 @@ class PathTracer:
         self._h = h
         self.width, self.height = width, height
         self.rank, self.world, self.partition = rank, world, partition
-        self.max_batch = min(max_batch if max_batch else 8, 16)
+        info = np.zeros(8, np.uint32)
+        self._check(L.pt_get_info(h, _ptr(info)), "pt_get_info")
+        self.max_batch, self.pipelines, self.queue_stride = int(info[0]), int(info[1]), int(info[2])
         self._scene = None
 
     def _check(self, rc, what):
@@ -331,9 +334,7 @@ class PathTracer:
 
     def debug_read_queue(self, queue: int, field: int) -> np.ndarray:
         cols = [1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4][field]
-        n_blocks = (self.max_batch * lib().pt_partition_count(self.width, self.height, self.partition, self.rank, self.world) + 255) // 256
-        stride = max((n_blocks + 63) // 64, 1) * 256 * 64  # 64 regions of whole shading blocks (csrc/kernels_trace.h)
-        out = np.zeros((cols, stride), np.uint32)
+        out = np.zeros((cols, self.queue_stride), np.uint32)
         st, cnt = c_uint32(), c_uint32()
         self._check(lib().pt_debug_read_queue(self._h, queue, field, _ptr(out), out.size, byref(st), byref(cnt)), "pt_debug_read_queue")
         return out, cnt.value

@@ -12,7 +12,7 @@
 #include "kernels_trace.h"
 
 #define PT_SHADE_BLOCK 256
-#define PT_MAX_BATCH 16   // frames (samples per pixel) traced together by one set of launches
+#define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
 
 // columns of one path queue; every array has `stride` entries per component
 struct PathQ {

@@ -267,10 +267,11 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 
 	c->n_paths = own_tiles(cfg->width, cfg->height, cfg->partition, cfg->rank, world) * 64u;
 	// Frames in flight per set of launches.  A trace launch costs ~0.25 ms of ramp-up and tail whatever its size
-	// (DESIGN.md "Batching"), so a batch is made as large as a modest memory budget allows: <= 2^25 paths (~12 GB).
-	c->max_batch = cfg->max_batch ? cfg->max_batch : 8u;
+	// (DESIGN.md "Batching"), so a batch is made as large as a modest memory budget allows: <= 2^26 paths (~23 GB of
+	// the 288 GB).  Measured at 1080p: 8 -> 6.89, 16 -> 7.24, 32 -> 7.40 Grays/s.
+	c->max_batch = cfg->max_batch ? cfg->max_batch : 16u;
 	if (c->max_batch > PT_MAX_BATCH) c->max_batch = PT_MAX_BATCH;
-	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 25)) c->max_batch--;
+	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 26)) c->max_batch--;
 	if (const char *e = getenv("PT355_BATCH")) { int v = atoi(e); if (v >= 1 && v <= PT_MAX_BATCH) c->max_batch = (uint32_t) v; }
 	// queue geometry: PT_SHARDS regions of `cap` slots, cap a whole number of shading blocks (kernels_trace.h)
 	{
@@ -587,6 +588,15 @@ int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, ui
 			if (kind[i] != 1) uv[2 * (size_t) i] = uv[2 * (size_t) i + 1] = 0.0f;
 		}
 	}
+	return PT_OK;
+}
+
+int pt_get_info(const pt_ctx *c, uint32_t info[8])
+{
+	if (!c || !info) return PT_EINVAL;
+	memset(info, 0, 8 * sizeof(uint32_t));
+	info[0] = c->max_batch; info[1] = c->n_pipes; info[2] = c->stride; info[3] = c->cap; info[4] = c->n_paths;
+	info[5] = (uint32_t) c->trace_grid;
 	return PT_OK;
 }
 
