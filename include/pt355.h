@@ -120,6 +120,9 @@ int pt_sync(pt_ctx *ctx);
  * rgba receives width*height*4 floats, row 0 = bottom row of the displayed image. */
 int pt_read_framebuffer(pt_ctx *ctx, float *rgba, size_t n_floats);
 int pt_clear_framebuffer(pt_ctx *ctx);
+/* Restores a running mean saved with pt_read_framebuffer (checkpoint/resume: the accumulation state is the image plus
+ * the next frame number; the reference keeps it only in the GL image and loses it on any input). */
+int pt_write_framebuffer(pt_ctx *ctx, const float *rgba, size_t n_floats);
 /* Device address of the RGBA32F image, for callers that move it with RCCL (torch.distributed). */
 int pt_framebuffer_device(pt_ctx *ctx, void **dev_ptr);
 

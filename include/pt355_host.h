@@ -80,6 +80,12 @@ int pth_scene_make_soup(pth_scene *s, uint32_t n_tris, uint32_t seed, float size
 
 /* shaders/framebuffer.frag:8-26: NaN -> red, Inf -> green, else pow(rgb, 1/2.2); 8-bit RGB out, top row first */
 int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8);
+/* Image files (no reference counterpart: it only blits to a window, src/main.cpp:108-120).  PPM: the tonemapped image.
+ * PFM: RGB float, bottom row first = the framebuffer's own row order; the accumulator's checkpoint format
+ * (pt_read_framebuffer -> pth_write_pfm ... pth_read_pfm -> pt_write_framebuffer, then continue at the next frame#). */
+int pth_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+int pth_write_pfm(const char *path, const float *rgba, uint32_t width, uint32_t height);
+int pth_read_pfm(const char *path, float *rgba, uint32_t width, uint32_t height);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,7 @@ EXPORTS = {
     "pt_sync": (c_int, [c_void_p]),
     "pt_read_framebuffer": (c_int, [c_void_p, c_void_p, c_size_t]),
     "pt_clear_framebuffer": (c_int, [c_void_p]),
+    "pt_write_framebuffer": (c_int, [c_void_p, c_void_p, c_size_t]),
     "pt_framebuffer_device": (c_int, [c_void_p, POINTER(c_void_p)]),
     "pt_trace_closest": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pt_trace_closest_device": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
@@ -100,6 +101,9 @@ EXPORTS = {
     "pth_scene_make_bunny": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_float, c_uint32]),
     "pth_scene_make_soup": (c_int, [c_void_p, c_uint32, c_uint32, c_float]),
     "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
+    "pth_write_ppm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
+    "pth_write_pfm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
+    "pth_read_pfm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
 }
 
 _lib = None
@@ -295,6 +299,10 @@ class PathTracer:
         self._check(lib().pt_read_framebuffer(self._h, _ptr(out), out.size), "pt_read_framebuffer")
         return out
 
+    def write_framebuffer(self, rgba):
+        a = np.ascontiguousarray(rgba, np.float32)
+        self._check(lib().pt_write_framebuffer(self._h, _ptr(a), a.size), "pt_write_framebuffer")
+
     def clear_framebuffer(self):
         self._check(lib().pt_clear_framebuffer(self._h), "pt_clear_framebuffer")
 
@@ -360,4 +368,21 @@ def tonemap_rgb8(rgba: np.ndarray) -> np.ndarray:
     h, w = rgba.shape[:2]
     out = np.zeros((h, w, 3), np.uint8)
     _check_host(lib().pth_tonemap_rgb8(_ptr(rgba), w, h, _ptr(out)), "pth_tonemap_rgb8")
+    return out
+
+
+def write_ppm(path: str, rgba: np.ndarray):
+    """Tonemap like shaders/framebuffer.frag and write a binary PPM (top row first)."""
+    rgb = tonemap_rgb8(rgba)
+    _check_host(lib().pth_write_ppm(path.encode(), _ptr(rgb), rgb.shape[1], rgb.shape[0]), "pth_write_ppm")
+
+
+def write_pfm(path: str, rgba: np.ndarray):
+    a = np.ascontiguousarray(rgba, np.float32)
+    _check_host(lib().pth_write_pfm(path.encode(), _ptr(a), a.shape[1], a.shape[0]), "pth_write_pfm")
+
+
+def read_pfm(path: str, width: int, height: int) -> np.ndarray:
+    out = np.zeros((height, width, 4), np.float32)
+    _check_host(lib().pth_read_pfm(path.encode(), _ptr(out), width, height), "pth_read_pfm")
     return out

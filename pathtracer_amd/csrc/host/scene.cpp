@@ -1,6 +1,7 @@
 // Scene container + procedural stand-in scenes + small host utilities (include/pt355_host.h).
 // Mirrors what src/main.cpp:18-63 assembles on the host before the six SSBO uploads.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -388,6 +389,48 @@ int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t
 			}
 		}
 	return PT_OK;
+}
+
+// Image files for a headless build (the reference only ever blits): binary PPM of the tonemapped image, and PFM
+// (RGB float, bottom row first -- the framebuffer's own row order) as the accumulator's checkpoint format.
+int pth_write_ppm(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height)
+{
+	if (!path || !rgb8) return PT_EINVAL;
+	FILE *f = fopen(path, "wb");
+	if (!f) return PT_EINVAL;
+	fprintf(f, "P6\n%u %u\n255\n", width, height);
+	const size_t n = (size_t) width * height * 3;
+	const bool ok = fwrite(rgb8, 1, n, f) == n;
+	return (fclose(f) == 0 && ok) ? PT_OK : PT_EINVAL;
+}
+
+int pth_write_pfm(const char *path, const float *rgba, uint32_t width, uint32_t height)
+{
+	if (!path || !rgba) return PT_EINVAL;
+	FILE *f = fopen(path, "wb");
+	if (!f) return PT_EINVAL;
+	fprintf(f, "PF\n%u %u\n-1.0\n", width, height); // negative scale: little-endian
+	bool ok = true;
+	for (size_t i = 0; i < (size_t) width * height && ok; i++) ok = fwrite(rgba + 4 * i, 4, 3, f) == 3;
+	return (fclose(f) == 0 && ok) ? PT_OK : PT_EINVAL;
+}
+
+int pth_read_pfm(const char *path, float *rgba, uint32_t width, uint32_t height)
+{
+	if (!path || !rgba) return PT_EINVAL;
+	FILE *f = fopen(path, "rb");
+	if (!f) return PT_EINVAL;
+	char tag[3] = {0, 0, 0};
+	unsigned w = 0, h = 0;
+	float scale = 0;
+	bool ok = fscanf(f, "%2s %u %u %f", tag, &w, &h, &scale) == 4 && tag[0] == 'P' && tag[1] == 'F' && w == width && h == height &&
+	          scale < 0 && fgetc(f) == '\n';
+	for (size_t i = 0; i < (size_t) width * height && ok; i++) {
+		ok = fread(rgba + 4 * i, 4, 3, f) == 3;
+		rgba[4 * i + 3] = 1.0f;
+	}
+	fclose(f);
+	return ok ? PT_OK : PT_EINVAL;
 }
 
 } // extern "C"

@@ -524,6 +524,18 @@ int pt_clear_framebuffer(pt_ctx *c)
 	return image_touched(c);
 }
 
+int pt_write_framebuffer(pt_ctx *c, const float *rgba, size_t n_floats)
+{
+	if (!c || !rgba) return PT_EINVAL;
+	const size_t need = (size_t) c->cfg.width * c->cfg.height * 4;
+	if (n_floats != need) return fail(c, PT_EINVAL, "pt_write_framebuffer: expected %zu floats, got %zu", need, n_floats);
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	{ int rc = join(c); if (rc) return rc; }
+	HIP_TRY(c, hipMemcpyAsync(c->fb, rgba, need * 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream)); // the caller's buffer may go away
+	return image_touched(c);
+}
+
 int pt_framebuffer_device(pt_ctx *c, void **dev_ptr)
 {
 	if (!c || !dev_ptr) return PT_EINVAL;

@@ -78,3 +78,24 @@ def test_tonemap_matches_the_blit_shader(pt):
     want = np.clip(np.round(np.power(np.array([0.0, 0.25, 1.0]), 1 / 2.2) * 255), 0, 255)
     assert np.abs(out[1, 2].astype(int) - want).max() <= 1
     assert out[0, 0].tolist()[0] == 255 and out[0, 0].tolist()[1] == 255
+
+
+def test_image_files_round_trip(pt, tmp_path):
+    rng = np.random.default_rng(0)
+    img = rng.uniform(0, 4, (24, 40, 4)).astype(np.float32)
+    img[..., 3] = 1.0
+    pfm = str(tmp_path / "a.pfm")
+    pt.write_pfm(pfm, img)
+    back = pt.read_pfm(pfm, 40, 24)
+    assert np.array_equal(back.view(np.uint32), img.view(np.uint32))
+    with pytest.raises(pt.PtError):
+        pt.read_pfm(pfm, 41, 24)
+    ppm = str(tmp_path / "a.ppm")
+    pt.write_ppm(ppm, img)
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n40 24\n255\n") and len(raw) == len(b"P6\n40 24\n255\n") + 40 * 24 * 3
+    assert np.array_equal(np.frombuffer(raw[-40 * 24 * 3:], np.uint8).reshape(24, 40, 3), pt.tonemap_rgb8(img))
+    # the diff tool reads what the library writes
+    import subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "imgdiff.py"), pfm, pfm], capture_output=True, text=True)
+    assert out.returncode == 0 and "bit-identical 100.0000 %" in out.stdout

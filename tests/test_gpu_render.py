@@ -119,3 +119,28 @@ def test_anyhit_mode_is_close(pt):
     assert rmse <= 0.03 * mean
     assert ca["node_steps"] < cr["node_steps"]
     assert float(any_[..., :3].mean()) <= mean * 1.0001  # any-hit can only remove light the quirk let through
+
+
+def test_checkpoint_resume(pt, tmp_path):
+    """Accumulation state = image + next frame number: saved as PFM, restored into a fresh context, continued."""
+    scene = pt.Scene.cornell(spheres=True)
+    seeds = pt.frame_seeds(0, 10)
+    whole, _ = _render(pt, scene, 64, 48, 10, 0)
+    c = pt.PathTracer(64, 48)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        c.render(0, seeds[:6], 5)
+        pt.write_pfm(str(tmp_path / "ckpt.pfm"), c.read_framebuffer())
+    finally:
+        c.close()
+    c = pt.PathTracer(64, 48)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        c.write_framebuffer(pt.read_pfm(str(tmp_path / "ckpt.pfm"), 64, 48))
+        c.render(6, seeds[6:], 5)
+        resumed = c.read_framebuffer()
+    finally:
+        c.close()
+    assert np.array_equal(whole.view(np.uint32), resumed.view(np.uint32))
