@@ -144,3 +144,57 @@ def test_checkpoint_resume(pt, tmp_path):
     finally:
         c.close()
     assert np.array_equal(whole.view(np.uint32), resumed.view(np.uint32))
+
+
+def _textured_scene(pt):
+    """A lit box whose floor, back wall and a GGX block sample three layers of the 512x512 RGB8 texture array
+    (calc_BRDF's texture() path, framebuffer.comp:599-603; GL_REPEAT + GL_LINEAR: uvs run past [0,1])."""
+    s = pt.Scene()
+    white = s.add_material([0.73, 0.73, 0.73], [0, 0, 0], [0, 0, 0])
+    floor = s.add_material([0.9, 0.9, 0.9], [0, 0, 0], [0, 0, 0], roughness=0.2, tex_index=0, mat_type=pt.MAT_OREN_NAYAR)
+    back = s.add_material([1.0, 1.0, 1.0], [0, 0, 0], [0, 0, 0], tex_index=1, mat_type=pt.MAT_LAMBERTIAN)
+    metal = s.add_material([0, 0, 0], [0.944, 0.776, 0.373], [0, 0, 0], roughness=0.15, tex_index=2, mat_type=pt.MAT_SPECULAR_METAL)
+    light = s.add_material([0, 0, 0], [0, 0, 0], [17, 12, 4], mat_type=pt.MAT_LIGHT)
+
+    def quad(a, b, c, d, mat, uvscale=1.0):
+        a, b, c, d = (np.array(p, np.float32) for p in (a, b, c, d))
+        n = np.cross(b - a, c - a)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32) * uvscale - 0.25
+        v = np.stack([np.concatenate([a, b, c]), np.concatenate([a, c, d])])
+        nn = np.tile(n, (2, 3))
+        uvs = np.stack([np.concatenate([uv[0], uv[1], uv[2]]), np.concatenate([uv[0], uv[2], uv[3]])])
+        s.add_triangles(v, nn, [mat, mat], uvs)
+
+    x0, x1, y0, y1, z0, z1 = -2.0, 2.0, -2.0, 2.0, -8.0, -4.0
+    quad([x0, y0, z1], [x1, y0, z1], [x1, y0, z0], [x0, y0, z0], floor, 3.0)
+    quad([x0, y0, z0], [x1, y0, z0], [x1, y1, z0], [x0, y1, z0], back, 2.0)
+    quad([x0, y1, z0], [x1, y1, z0], [x1, y1, z1], [x0, y1, z1], white)
+    quad([x0, y0, z1], [x0, y0, z0], [x0, y1, z0], [x0, y1, z1], white)
+    quad([x1, y0, z0], [x1, y0, z1], [x1, y1, z1], [x1, y1, z0], white)
+    quad([-0.5, 1.99, -6.5], [0.5, 1.99, -6.5], [0.5, 1.99, -5.5], [-0.5, 1.99, -5.5], light)
+    quad([-1.2, -1.0, -5.5], [0.2, -1.0, -5.2], [0.2, -1.0, -6.6], [-1.2, -1.0, -6.9], metal, 1.5)   # tilted-ish slab top
+    quad([-1.2, -2.0, -5.5], [0.2, -2.0, -5.2], [0.2, -1.0, -5.2], [-1.2, -1.0, -5.5], metal, 1.0)   # its front
+    s.finalize()
+    rng = np.random.default_rng(12)
+    tex = rng.integers(0, 256, (3, 512, 512, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:512, 0:512]
+    tex[0] = np.stack([((xx // 32 + yy // 32) % 2) * 200 + 30, xx // 2, yy // 2], 2).astype(np.uint8)  # checker + ramps
+    return s, tex
+
+
+def test_textured_materials(pt, ol):
+    scene, tex = _textured_scene(pt)
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 4)
+    c = pt.PathTracer(96, 96, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+    try:
+        c.upload_scene(scene, tex_rgb8=tex)
+        c.set_camera(cam)
+        c.render(0, seeds, 5)
+        img = c.read_framebuffer()
+    finally:
+        c.close()
+    ref, _ = ol.render(ol.scene_from_desc(scene.desc(), tex_rgb8=tex), cam, 96, 96, seeds)
+    untextured, _ = ol.render(ol.scene_from_desc(scene.desc()), cam, 96, 96, seeds)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert not np.array_equal(ref, untextured)  # the layers are really being sampled
