@@ -104,6 +104,13 @@ int pt_upload_scene(pt_ctx *ctx, const pt_scene_desc *scene);
 /* Replaces: glNamedBufferSubData(cam.cam_ubo, ...) of src/main.cpp:90-94 (CameraGLSL = 12 floats). */
 int pt_set_camera(pt_ctx *ctx, const float cam[12]);
 
+/* Replaces: editing shaders/framebuffer.comp:1109-1111, where the reference selects one of its three estimators by
+ * (un)commenting a line.  MIS (the live one) is the default. */
+#define PT_ESTIMATOR_MIS  0u /* estimator_path_tracing_mis,  framebuffer.comp:874-1081 */
+#define PT_ESTIMATOR_NEE  1u /* estimator_path_tracing_nee,  framebuffer.comp:725-867 */
+#define PT_ESTIMATOR_BRDF 2u /* estimator_path_tracing_BRDF, framebuffer.comp:647-693 */
+int pt_set_estimator(pt_ctx *ctx, uint32_t estimator);
+
 /* Replaces: one iteration of src/main.cpp:97-101 -- FrameData upload, glDispatchCompute(W/8,H/8,1),
  * glMemoryBarrier.  frame_data = {seed, frame#, bounces, 0}.  One sample per pixel, blended into the
  * running mean with weight 1/(frame#+1) (framebuffer.comp:1124-1129).  Asynchronous on the context's

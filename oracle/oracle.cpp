@@ -819,8 +819,127 @@ v3 estimator_path_tracing_mis(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_
 	return color;
 }
 
+// Light sampling shared by the NEE and MIS estimators (fc:765-808 == fc:926-956): 1 raw draw + 2 rand draws.
+struct LightSample { v3 y; float area; Mat mat; };
+LightSample sample_light(Ctx &cx, uint32_t num_light_sources, uint32_t &rng_state)
+{
+	const Scene &sc = cx.sc;
+	LightSample L;
+	L.y = V(0, 0, 0); L.area = 0.0f;
+	memset(&L.mat, 0, sizeof L.mat);
+	int picked = (int) (pcg(rng_state) % num_light_sources);
+	if (sc.n_light_tris > 0 && picked < (int) sc.n_light_tris) {
+		const Tri &ls = sc.tris[sc.light_tris[picked]];
+		L.area = area_triangle(ls);
+		L.mat = sc.mats[ls.d4[3]];
+		float r1 = rnd(rng_state), r2 = rnd(rng_state);
+		L.y = map_to_triangle(r1, r2, V(ls.d1[0], ls.d1[1], ls.d1[2]), V(ls.d2[0], ls.d2[1], ls.d2[2]), V(ls.d3[0], ls.d3[1], ls.d3[2]));
+	} else if (sc.n_light_spheres > 0) {
+		const Sph &ls = sc.spheres[sc.light_spheres[picked - (int) sc.n_light_tris]];
+		float radius = ls.d[3];
+		L.area = area_sphere(radius);
+		L.mat = sc.mats[ls.mat[0]];
+		float r1 = rnd(rng_state), r2 = rnd(rng_state);
+		L.y = map_to_unit_sphere(cx.fn, r1, r2) * radius + V(ls.d[0], ls.d[1], ls.d[2]);
+	}
+	return L;
+}
+
+// fc:647-693 -- BSDF sampling only (commented out at fc:1109; ORACLE_FLAG_EST_BRDF selects it)
+v3 estimator_path_tracing_BRDF(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_t frame_bounces)
+{
+	const Scene &sc = cx.sc;
+	v3 color = V(0, 0, 0);
+	v3 throughput_term = V(1, 1, 1);
+	for (uint32_t b = 0; b < frame_bounces; b++) {
+		Hit data;
+		if (b == 0) cx.cn.prim++; else cx.cn.bounce++;
+		if (!intersect(sc, ro, rd, data, cx.cn)) {
+			color = color + throughput_term * sky_color(cx, rd) * ENVIRONMENT_MAP_LE;
+			return color;
+		}
+		Mat mat = sc.mats[data.mat];
+		m3 tnb = tnb_rows(hn(data.n));
+		m3 inverse_tnb = inverse(tnb);
+		color = color + throughput_term * le_of(mat);
+		ro = (ro + (rd * h2f(data.t))) + (NORMAL_OFFSET * hn(data.n));
+		float pdf, cos_theta;
+		v3 wm;
+		v3 wo = normalize(mul(tnb, -rd));
+		v3 wi = pick_wi(cx.fn, wo, mat, false, &wm, &cos_theta, &pdf, rng_state);
+		rd = normalize(mul(inverse_tnb, wi));
+		v3 BRDF = calc_BRDF(cx, wo, wm, wi, mat, data.uv, false);
+		throughput_term = throughput_term * ((cos_theta * BRDF) / pdf); // fc:689: cos_theta * BRDF / pdf
+	}
+	return color;
+}
+
+// fc:725-867 -- next-event estimation only (commented out at fc:1110; ORACLE_FLAG_EST_NEE selects it)
+v3 estimator_path_tracing_nee(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_t frame_bounces)
+{
+	const Scene &sc = cx.sc;
+	v3 color = V(0, 0, 0);
+	v3 throughput_term = V(1, 1, 1);
+	bool prev_bounce_specular = false;
+	for (uint32_t bounce = 0; bounce < frame_bounces; bounce++) {
+		Hit data;
+		if (bounce == 0) cx.cn.prim++; else cx.cn.bounce++;
+		if (!intersect(sc, ro, rd, data, cx.cn)) {
+			color = color + throughput_term * sky_color(cx, rd) * ENVIRONMENT_MAP_LE;
+			return color;
+		}
+		m3 tnb = tnb_rows(hn(data.n));
+		m3 inverse_tnb = inverse(tnb);
+		v3 wo = normalize(mul(tnb, -rd));
+		Mat mat = sc.mats[data.mat];
+		uint32_t num_light_sources = sc.n_light_tris + sc.n_light_spheres;
+		bool can_use_NEE = num_light_sources > 0;
+		can_use_NEE = can_use_NEE && (mat.d2[3] == 0.0f || mat.d2[3] == 1.0f ||
+		                              (mat.d2[3] == 2.0f && mat.d1[3] * mat.d1[3] > NEE_SPECULAR_ROUGHNESS_CUTOFF));
+		if (mat.d2[3] == -1.0f) {
+			if (bounce == 0 || (bounce > 0 && prev_bounce_specular)) color = color + throughput_term * le_of(mat);
+			return color;
+		} else if (can_use_NEE) {
+			v3 direct_illumination = V(0, 0, 0);
+			float pdf_pick_light = 1.0f / (float) num_light_sources;
+			LightSample L = sample_light(cx, num_light_sources, rng_state);
+			float pdf_pick_point_on_light = 1.0f / L.area;
+			float pdf_light_area = pdf_pick_light * pdf_pick_point_on_light;
+			v3 shadow_ro = (ro + rd * h2f(data.t)) + NORMAL_OFFSET * hn(data.n);
+			v3 dist_vec = L.y - shadow_ro;
+			v3 shadow_rd = normalize(dist_vec);
+			Hit shadow_data;
+			cx.cn.shadow++;
+			bool shadow_hit_anything = intersect(sc, shadow_ro, shadow_rd, shadow_data, cx.cn);
+			v3 shadow_ray_hit = shadow_ro + shadow_rd * h2f(shadow_data.t);
+			v3 dl = L.y - shadow_ray_hit;
+			if (shadow_hit_anything && fabsf(dl.x) <= FLOAT_COMPARE && fabsf(dl.y) <= FLOAT_COMPARE && fabsf(dl.z) <= FLOAT_COMPARE) {
+				v3 wi = normalize(mul(tnb, shadow_rd));
+				v3 wm = normalize(mul(tnb, hn(data.n)));
+				v3 BRDF = calc_BRDF(cx, wo, wm, wi, mat, data.uv, true);
+				float cos_theta_x = fmax_(0.0f, dot(hn(data.n), shadow_rd));
+				float cos_theta_y = fmax_(0.0f, dot(hn(shadow_data.n), -shadow_rd));
+				float squared_dist = dot(dist_vec, dist_vec);
+				float G = cos_theta_x * cos_theta_y / squared_dist;
+				direct_illumination = direct_illumination + le_of(L.mat) * BRDF * G / pdf_light_area;
+			}
+			direct_illumination = direct_illumination / 1.0f;
+			color = color + throughput_term * direct_illumination;
+		}
+		ro = ro + (rd * h2f(data.t) + NORMAL_OFFSET * hn(data.n)); // fc:848: ro += rd*t + offset*n
+		v3 wm;
+		float cos_theta_x, pdf;
+		v3 wi = pick_wi(cx.fn, wo, mat, true, &wm, &cos_theta_x, &pdf, rng_state);
+		rd = normalize(mul(inverse_tnb, wi));
+		v3 BRDF = calc_BRDF(cx, wo, wm, wi, mat, data.uv, true);
+		prev_bounce_specular = (mat.d2[3] == 2.0f && mat.d1[3] * mat.d1[3] <= NEE_SPECULAR_ROUGHNESS_CUTOFF);
+		throughput_term = throughput_term * (BRDF * cos_theta_x / pdf);
+	}
+	return color;
+}
+
 // fc:1088-1112
-v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int py, uint32_t rng_state, uint32_t bounces)
+v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int py, uint32_t rng_state, uint32_t bounces, uint32_t flags)
 {
 	v3 cam_origin = V(cam[0], cam[1], cam[2]);
 	v3 cam_forward = V(cam[4], cam[5], cam[6]);
@@ -838,6 +957,9 @@ v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int
 	float v = ((float) py + oy) / sh;
 	v3 point_on_grid = (grid_origin + u * grid_x) + v * grid_y;
 	v3 ray_direction = normalize(point_on_grid - cam_origin);
+	// fc:1109-1111: the reference picks the estimator by (un)commenting one of these three lines
+	if (flags & ORACLE_FLAG_EST_BRDF) return estimator_path_tracing_BRDF(cx, cam_origin, ray_direction, rng_state, bounces);
+	if (flags & ORACLE_FLAG_EST_NEE) return estimator_path_tracing_nee(cx, cam_origin, ray_direction, rng_state, bounces);
 	return estimator_path_tracing_mis(cx, cam_origin, ray_direction, rng_state, bounces);
 }
 
@@ -890,7 +1012,7 @@ int oracle_render(const oracle_scene *s, const float cam[12], uint32_t width, ui
 						uint32_t rng_state = seed3(px, py, seed); // fc:1120
 						cx.cn.paths++;
 						cx.dbg = dbg_px == (int) (py * width + px);
-						v3 color = render_function(cx, cam, (float) width, (float) height, (int) px, (int) py, rng_state, bounces);
+						v3 color = render_function(cx, cam, (float) width, (float) height, (int) px, (int) py, rng_state, bounces, flags);
 						float *p = rgba + ((size_t) py * width + px) * 4; // fc:1126-1129
 						float fa = (float) frame / (float) (frame + 1), fb = 1.0f / (float) (frame + 1);
 						p[0] = fa * p[0] + fb * color.x;

@@ -42,6 +42,8 @@ typedef struct oracle_counters {
 } oracle_counters;
 
 #define ORACLE_FLAG_LIBM 1u /* transcendental functions from glibc instead of the spec'd ptm_* forms */
+#define ORACLE_FLAG_EST_NEE  2u /* estimator_path_tracing_nee  (framebuffer.comp:725-867) instead of the MIS estimator */
+#define ORACLE_FLAG_EST_BRDF 4u /* estimator_path_tracing_BRDF (framebuffer.comp:647-693) */
 
 /* intersect() of framebuffer.comp:423-456 for a batch of rays (AoS xyz).
  * kind: 0 miss, 1 triangle, 2 sphere.  prim: full 32-bit index.  t_h: fp16 bits.

@@ -19,6 +19,7 @@ PT_FLAG_SHADOW_ANYHIT = 1
 PT_FLAG_TRACE_DEAD_PATHS = 2
 PT_FLAG_COUNT_TRAVERSAL = 4
 PT_FLAG_SHADOW_FULL_TRAVERSAL = 8
+PT_ESTIMATOR_MIS, PT_ESTIMATOR_NEE, PT_ESTIMATOR_BRDF = 0, 1, 2
 PT_PARTITION_TILES = 0
 PT_PARTITION_FULL = 1
 MAT_LIGHT, MAT_LAMBERTIAN, MAT_OREN_NAYAR, MAT_SPECULAR_METAL = -1, 0, 1, 2
@@ -60,6 +61,7 @@ EXPORTS = {
     "pt_last_error": (c_char_p, [c_void_p]),
     "pt_upload_scene": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
     "pt_set_camera": (c_int, [c_void_p, c_void_p]),
+    "pt_set_estimator": (c_int, [c_void_p, c_uint32]),
     "pt_render_frame": (c_int, [c_void_p, c_void_p]),
     "pt_render": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32]),
     "pt_sync": (c_int, [c_void_p]),
@@ -282,6 +284,9 @@ class PathTracer:
     def set_camera(self, cam12):
         cam = np.ascontiguousarray(cam12, np.float32).reshape(12)
         self._check(lib().pt_set_camera(self._h, _ptr(cam)), "pt_set_camera")
+
+    def set_estimator(self, which: int):
+        self._check(lib().pt_set_estimator(self._h, which), "pt_set_estimator")
 
     def render_frame(self, seed: int, frame: int, bounces: int = 5):
         fd = np.array([seed, frame, bounces, 0], np.uint32)

@@ -12,6 +12,9 @@
 #include "kernels_trace.h"
 
 #define PT_SHADE_BLOCK 256
+#define PT_EST_MIS 0u   // estimator_path_tracing_mis,  fc:874-1081 (the live one, fc:1111)
+#define PT_EST_NEE 1u   // estimator_path_tracing_nee,  fc:725-867
+#define PT_EST_BRDF 2u  // estimator_path_tracing_BRDF, fc:647-693
 #define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
 
 // columns of one path queue; every array has `stride` entries per component
@@ -41,6 +44,7 @@ struct ShadeArgs {
 	uint32_t width, height;
 	uint32_t bounces;
 	uint32_t stage;         // 0: after the primary trace; k: after the trace of bounce k
+	uint32_t estimator;     // PT_EST_*
 	uint32_t flags;
 	float4 *sample;         // [n_batch][n_paths_frame]: the finished sample of every path of the batch
 	float *fb;
@@ -311,22 +315,121 @@ PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint3
 	return y * width + x;
 }
 
+// Light sampling shared by the MIS and NEE estimators (fc:926-956 == fc:765-808): one raw draw picks the light, two
+// rand draws the point on it.
+struct LightPick { v3 y, le; float area; };
+PT_DEV LightPick sample_light(const DevScene &sc, uint32_t num_light_sources, uint32_t &rng)
+{
+	LightPick L;
+	L.y = V(0.0f, 0.0f, 0.0f); L.le = V(0.0f, 0.0f, 0.0f); L.area = 0.0f;
+	const int picked = (int) (pcg(rng) % num_light_sources);
+	if (sc.n_light_tris > 0u && picked < (int) sc.n_light_tris) {
+		uint32_t li = sc.light_tris[picked];
+		if (li >= sc.n_tris) li = 0;
+		const float4 *tp = sc.tris + 4u * (size_t) li;
+		const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
+		const uint4 d4 = *(const uint4 *) (tp + 3);
+		L.area = area_triangle(sc, li);
+		const MatRec lm = load_mat(sc, d4.w);
+		L.le = V(lm.d3.x, lm.d3.y, lm.d3.z);
+		float r1 = rnd(rng), r2 = rnd(rng);
+		if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; } // fc:707-723
+		const v3 v0 = V(d1.x, d1.y, d1.z);
+		const v3 pnt = r1 * (V(d2.x, d2.y, d2.z) - v0) + r2 * (V(d3.x, d3.y, d3.z) - v0);
+		L.y = pnt + v0;
+	} else if (sc.n_light_spheres > 0u) {
+		uint32_t si = sc.light_spheres[picked - (int) sc.n_light_tris];
+		if (si >= sc.n_spheres) si = 0;
+		const float4 s = sc.spheres[2u * si];
+		const uint4 sm = *(const uint4 *) (sc.spheres + 2u * si + 1);
+		L.area = area_sphere(s.w);
+		const MatRec lm = load_mat(sc, sm.x);
+		L.le = V(lm.d3.x, lm.d3.y, lm.d3.z);
+		const float r1 = rnd(rng), r2 = rnd(rng);
+		L.y = map_to_unit_sphere(r1, r2) * s.w + V(s.x, s.y, s.z);
+	}
+	return L;
+}
+
+// fc:563-589.  using_NEE (the NEE estimator) turns GGX importance sampling off: metals are cosine-sampled too.
+PT_DEV v3 pick_wi(v3 wo, const MatRec &mat, bool using_nee, v3 *wm, float *cos_theta, float *pdf, uint32_t &rng)
+{
+	const float ty = mat.d2.w;
+	const bool is_ggx = !using_nee;
+	if (ty == -1.0f || ty == 0.0f || ty == 1.0f || (ty == 2.0f && !is_ggx)) {
+		*wm = V(0.0f, 1.0f, 0.0f);
+		const float r1 = rnd(rng), r2 = rnd(rng);
+		const v3 wi = normalize(map_to_unit_sphere(r1, r2) + *wm);
+		*cos_theta = dot(*wm, wi);
+		*pdf = *cos_theta / PT_PI;
+		return wi;
+	}
+	if (ty == 2.0f) {
+		*cos_theta = 1.0f;
+		*pdf = 1.0f;
+		const float alpha_ggx = mat.d1.w;
+		const float a2 = alpha_ggx * alpha_ggx;
+		const float e1 = rnd(rng), e2 = rnd(rng);
+		const float theta = ptm_acos(__builtin_sqrtf((1.0f - e1) / ((a2 - 1.0f) * e1 + 1.0f)));
+		const float phi = PT_TWO_PI * e2;
+		float s_t, c_t, s_p, c_p;
+		ptm_sincos(theta, &s_t, &c_t);
+		ptm_sincos(phi, &s_p, &c_p);
+		*wm = V(s_t * c_p, c_t, s_t * s_p);
+		const v3 I = -wo;
+		return normalize(I - (2.0f * dot(*wm, I)) * *wm);
+	}
+	*wm = V(0.0f, 0.0f, 0.0f); *cos_theta = 0.0f; *pdf = 0.0f;
+	return V(__builtin_inff(), __builtin_inff(), __builtin_inff());
+}
+
+// Compaction into the next queue: ballot + mbcnt inside a wave, the four wave counts through LDS, ONE returning
+// atomic per block on the fill counter of the block's output region.  Every thread of the block must call it.
+// Returns the slot for a live lane.  n_rays_bounce / shadow: lanes that enqueue a ray of that kind (counted here).
+PT_DEV uint32_t claim_slot(const ShadeArgs &a, bool alive, bool bounce_ray, bool shadow_ray)
+{
+	__shared__ uint32_t s_live[PT_SHADE_BLOCK / 64], s_b[PT_SHADE_BLOCK / 64], s_s[PT_SHADE_BLOCK / 64], s_base;
+	const unsigned long long live = __ballot(alive);
+	const unsigned long long bm = __ballot(bounce_ray), sm = __ballot(shadow_ray);
+	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+	if (lane == 0) { s_live[wv] = (uint32_t) __popcll(live); s_b[wv] = (uint32_t) __popcll(bm); s_s[wv] = (uint32_t) __popcll(sm); }
+	__syncthreads();
+	const uint32_t out_region = blockIdx.x % PT_SHARDS;
+	if (threadIdx.x == 0) {
+		uint32_t tot = 0, nb = 0, ns = 0;
+		for (uint32_t w = 0; w < PT_SHADE_BLOCK / 64; w++) { tot += s_live[w]; nb += s_b[w]; ns += s_s[w]; }
+		uint32_t base = 0;
+		if (tot) base = atomicAdd(&a.ctl->qcount[a.in_q ^ 1u][out_region * PT_SHARD_STRIDE], tot);
+		// rays are counted when they are enqueued
+		if (nb) atomicAdd(&a.ctl->rays_bounce[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) nb);
+		if (ns) atomicAdd(&a.ctl->rays_shadow[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) ns);
+		s_base = base;
+	}
+	__syncthreads();
+	uint32_t o = out_region * a.cap + s_base;
+	for (uint32_t w = 0; w < wv; w++) o += s_live[w];
+	o += __builtin_amdgcn_mbcnt_hi((uint32_t) (live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) live, 0u));
+	return o;
+}
+
 // main() + render_function(), fc:1088-1122: seed, pixel jitter, pinhole ray -- for every pixel this rank owns, for
 // every frame of the batch.  Path p (frame slot p / n_paths_frame) starts in region p / per_region of queue 0.
 __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
 {
 	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n_total = a.n_batch * a.n_paths_frame;
+	const bool no_rays = a.estimator != PT_EST_MIS && a.bounces == 0u; // the alternative estimators' loops never run
 	if (p == 0) {
 		atomicAdd(&a.ctl->paths, (unsigned long long) n_total);
-		atomicAdd(&a.ctl->rays_primary, (unsigned long long) n_total);
+		if (!no_rays) atomicAdd(&a.ctl->rays_primary, (unsigned long long) n_total);
 	}
 	if (p < PT_SHARDS) {
 		const uint32_t lo = p * a.per_region;
-		a.ctl->qcount[0][p * PT_SHARD_STRIDE] = n_total > lo ? (n_total - lo < a.per_region ? n_total - lo : a.per_region) : 0u;
+		a.ctl->qcount[0][p * PT_SHARD_STRIDE] = (n_total > lo && !no_rays) ? (n_total - lo < a.per_region ? n_total - lo : a.per_region) : 0u;
 		a.ctl->shard[p * PT_SHARD_STRIDE] = 0;
 	}
 	if (p >= n_total) return;
+	if (no_rays) { a.sample[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }
 	const uint32_t fslot = p / a.n_paths_frame;
 	const uint32_t pixel = path_pixel(p - fslot * a.n_paths_frame, a.width, a.partition, a.rank, a.world);
 	const uint32_t px = pixel % a.width, py = pixel / a.width;
@@ -392,7 +495,6 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_resolve(ShadeArgs a)
 // bounce hits of bounce k (fc:970-1077) and, unless k == bounces, emits bounce k+1 (fc:901-968, 1009-1017).
 __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 {
-	__shared__ uint32_t s_live[PT_SHADE_BLOCK / 64], s_nee[PT_SHADE_BLOCK / 64], s_base;
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t in_region = blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size
 	const uint32_t n_in = a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
@@ -497,36 +599,15 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 		alive = false;
 	}
 
-	// ---- claim slots of the next queue: one returning atomic per block, on the block's own output region
+	// ---- claim a slot of the next queue
 	const uint32_t num_ls = num_light_sources;
 	bool can_use_nee = false;
 	if (alive) { // fc:914-915 for the vertex the next bounce leaves from (x = y, mat_x = mat_y)
 		const float a2 = mat_y.d1.w * mat_y.d1.w;
 		can_use_nee = num_ls > 0u && (mat_y.d2.w == 0.0f || mat_y.d2.w == 1.0f || (mat_y.d2.w == 2.0f && a2 > 0.0f));
 	}
-	const unsigned long long live = __ballot(alive);
-	const unsigned long long sh_mask = __ballot(can_use_nee);
-	const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-	if (lane == 0) { s_live[wv] = (uint32_t) __popcll(live); s_nee[wv] = (uint32_t) __popcll(sh_mask); }
-	__syncthreads();
-	const uint32_t out_region = blockIdx.x % PT_SHARDS;
-	if (threadIdx.x == 0) {
-		uint32_t tot = 0, nee = 0;
-		for (uint32_t w = 0; w < PT_SHADE_BLOCK / 64; w++) { tot += s_live[w]; nee += s_nee[w]; }
-		uint32_t base = 0;
-		if (tot) {
-			base = atomicAdd(&a.ctl->qcount[a.in_q ^ 1u][out_region * PT_SHARD_STRIDE], tot);
-			// rays are counted when they are enqueued
-			atomicAdd(&a.ctl->rays_bounce[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) tot);
-			if (nee) atomicAdd(&a.ctl->rays_shadow[out_region * (PT_SHARD_STRIDE / 2)], (unsigned long long) nee);
-		}
-		s_base = base;
-	}
-	__syncthreads();
+	const uint32_t o = claim_slot(a, alive, alive, can_use_nee);
 	if (!alive) return;
-	uint32_t o = out_region * a.cap + s_base;
-	for (uint32_t w = 0; w < wv; w++) o += s_live[w];
-	o += __builtin_amdgcn_mbcnt_hi((uint32_t) (live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) live, 0u));
 
 	// ---- emit bounce b = stage + 1 from x = y (fc:901-968, 1009-1017)
 	const v3 x = y;
@@ -538,35 +619,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 	uint32_t new_meta = (can_use_nee ? 3u : 0u) | (mat_x.d2.w == 2.0f ? 4u : 0u);
 	if (can_use_nee) {
 		const float pdf_pick_light = 1.0f / (float) num_light_sources;
-		const int picked = (int) (pcg(rng) % num_light_sources);
-		float light_area = 0.0f;
-		v3 y_nee = V(0.0f, 0.0f, 0.0f);
-		v3 le = V(0.0f, 0.0f, 0.0f);
-		if (sc.n_light_tris > 0u && picked < (int) sc.n_light_tris) {
-			uint32_t li = sc.light_tris[picked];
-			if (li >= sc.n_tris) li = 0;
-			const float4 *tp = sc.tris + 4u * (size_t) li;
-			const float4 d1 = tp[0], d2 = tp[1], d3 = tp[2];
-			const uint4 d4 = *(const uint4 *) (tp + 3);
-			light_area = area_triangle(sc, li);
-			const MatRec lm = load_mat(sc, d4.w);
-			le = V(lm.d3.x, lm.d3.y, lm.d3.z);
-			float r1 = rnd(rng), r2 = rnd(rng);
-			if (r1 + r2 > 1.0f) { r1 = 1.0f - r1; r2 = 1.0f - r2; } // fc:707-723
-			const v3 v0 = V(d1.x, d1.y, d1.z);
-			const v3 pnt = r1 * (V(d2.x, d2.y, d2.z) - v0) + r2 * (V(d3.x, d3.y, d3.z) - v0);
-			y_nee = pnt + v0;
-		} else if (sc.n_light_spheres > 0u) {
-			uint32_t si = sc.light_spheres[picked - (int) sc.n_light_tris];
-			if (si >= sc.n_spheres) si = 0;
-			const float4 s = sc.spheres[2u * si];
-			const uint4 sm = *(const uint4 *) (sc.spheres + 2u * si + 1);
-			light_area = area_sphere(s.w);
-			const MatRec lm = load_mat(sc, sm.x);
-			le = V(lm.d3.x, lm.d3.y, lm.d3.z);
-			const float r1 = rnd(rng), r2 = rnd(rng);
-			y_nee = map_to_unit_sphere(r1, r2) * s.w + V(s.x, s.y, s.z);
-		}
+		const LightPick L = sample_light(sc, num_light_sources, rng);
+		const float light_area = L.area;
+		const v3 y_nee = L.y, le = L.le;
 		const v3 dist_vec = y_nee - x;
 		const v3 shadow_rd = normalize(dist_vec);
 		const float squared_dist = dot(dist_vec, dist_vec);
@@ -585,33 +640,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 	}
 	const v3 new_ro = x + PT_NORMAL_OFFSET * normal_x; // fc:1009
 
-	// pick_wi, fc:563-589 (using_NEE = false)
-	v3 wm = V(0.0f, 0.0f, 0.0f), wi;
-	float cos_theta_x = 0.0f, pdf_bsdf_sa = 0.0f;
-	const float ty = mat_x.d2.w;
-	if (ty == -1.0f || ty == 0.0f || ty == 1.0f) {
-		wm = V(0.0f, 1.0f, 0.0f);
-		const float r1 = rnd(rng), r2 = rnd(rng);
-		wi = normalize(map_to_unit_sphere(r1, r2) + wm);
-		cos_theta_x = dot(wm, wi);
-		pdf_bsdf_sa = cos_theta_x / PT_PI;
-	} else if (ty == 2.0f) {
-		cos_theta_x = 1.0f;
-		pdf_bsdf_sa = 1.0f;
-		const float alpha_ggx = mat_x.d1.w;
-		const float a2 = alpha_ggx * alpha_ggx;
-		const float e1 = rnd(rng), e2 = rnd(rng);
-		const float theta = ptm_acos(__builtin_sqrtf((1.0f - e1) / ((a2 - 1.0f) * e1 + 1.0f)));
-		const float phi = PT_TWO_PI * e2;
-		float s_t, c_t, s_p, c_p;
-		ptm_sincos(theta, &s_t, &c_t);
-		ptm_sincos(phi, &s_p, &c_p);
-		wm = V(s_t * c_p, c_t, s_t * s_p);
-		const v3 I = -wo;
-		wi = normalize(I - (2.0f * dot(wm, I)) * wm);
-	} else {
-		wi = V(__builtin_inff(), __builtin_inff(), __builtin_inff());
-	}
+	v3 wm;
+	float cos_theta_x, pdf_bsdf_sa;
+	const v3 wi = pick_wi(wo, mat_x, false, &wm, &cos_theta_x, &pdf_bsdf_sa, rng);
 	const v3 new_rd = normalize(mul(inverse_tnb, wi));
 	const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, false);
 
@@ -625,6 +656,144 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
 	st3(a.out.bs, o, st, brdf);
 	a.out.bs[3 * (size_t) st + o] = cos_theta_x;
 	a.out.bs[4 * (size_t) st + o] = pdf_bsdf_sa;
+}
+
+// The two estimators the reference keeps commented out at fc:1109-1110, as wavefront stages.  Stage b consumes the
+// hit of the loop's b-th intersect() (fc:659 / fc:735).  NEE estimator: the shadow ray emitted at stage b is resolved
+// at the head of stage b+1 (nothing else touches `color` in between, so the order of additions is the shader's), and
+// a last stage b == bounces only resolves.  Queue columns are reused: nee = Le*BRDF (3), cos_x, d^2, y (3);
+// bs = throughput before this bounce (3), pdf_light_area.  meta bit0: shadow ray present, bit3: prev_bounce_specular.
+__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_alt(ShadeArgs a)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t in_region = blockIdx.x / a.blocks_per_region;
+	const uint32_t n_in = a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
+	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
+	const uint32_t st = a.stride;
+	const DevScene &sc = a.sc;
+	const bool nee_est = a.estimator == PT_EST_NEE;
+	bool alive = i - in_region * a.cap < n_in;
+	bool emit_bounce = false, emit_shadow = false;
+
+	uint32_t pid = 0, rng = 0, meta = 0, new_meta = 0;
+	v3 thr = V(0, 0, 0), col = V(0, 0, 0), ro = V(0, 0, 0), rd = V(0, 0, 0);
+	v3 new_ro = V(0, 0, 0), new_rd = V(0, 0, 0), s_ro = V(0, 0, 0), s_rd = V(0, 0, 0), s_lb = V(0, 0, 0), s_y = V(0, 0, 0), thr_old = V(0, 0, 0);
+	float s_cos = 0.0f, s_d2 = 0.0f, s_pdf = 0.0f;
+
+	if (alive) {
+		pid = a.in.pix[i]; rng = a.in.rng[i]; meta = a.in.meta[i];
+		thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
+		ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
+		// ---- NEE of the previous stage (fc:815-842)
+		if (nee_est && (meta & 1u)) {
+			v3 direct = V(0.0f, 0.0f, 0.0f);
+			const uint4 srec = a.in.shit[i];
+			if ((srec.y >> 16) != 0u) {
+				const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
+				const HitRec sh = hit_attributes(sc, srec.x, srec.y, __uint_as_float(srec.z), __uint_as_float(srec.w), sro, srd);
+				const v3 y_l = ld3(a.in.nee + 5 * (size_t) st, i, st);
+				const v3 dl = y_l - (sro + srd * sh.t);
+				if (__builtin_fabsf(dl.x) <= PT_FLOAT_COMPARE && __builtin_fabsf(dl.y) <= PT_FLOAT_COMPARE && __builtin_fabsf(dl.z) <= PT_FLOAT_COMPARE) {
+					const v3 lb = ld3(a.in.nee, i, st);
+					const float cos_x = a.in.nee[3 * (size_t) st + i], d2 = a.in.nee[4 * (size_t) st + i];
+					const float pdf_light_area = a.in.bs[3 * (size_t) st + i];
+					const float cos_y = fmax_(0.0f, dot(sh.n, -srd));
+					const float G = cos_x * cos_y / d2;
+					direct = direct + lb * G / pdf_light_area;
+				}
+			}
+			direct = direct / 1.0f;
+			col = col + ld3(a.in.bs, i, st) * direct;
+		}
+		if (nee_est && a.stage == a.bounces) {
+			accumulate(a, pid, col);
+			alive = false;
+		} else {
+			const uint4 hrec = a.in.hit[i];
+			if ((hrec.y >> 16) == 0u) {
+				col = col + thr * sky_color(sc, rd) * 1.0f; // fc:662 / fc:738
+				accumulate(a, pid, col);
+				alive = false;
+			} else {
+				const HitRec data = hit_attributes(sc, hrec.x, hrec.y, __uint_as_float(hrec.z), __uint_as_float(hrec.w), ro, rd);
+				const MatRec mat = load_mat(sc, data.mat);
+				const v3 le = V(mat.d3.x, mat.d3.y, mat.d3.z);
+				const m3 tnb = tnb_rows(data.n);
+				const m3 inverse_tnb = inverse(tnb);
+				const v3 wo = normalize(mul(tnb, -rd));
+				const bool last = a.stage + 1u == a.bounces;
+				if (!nee_est) {
+					// fc:666-689
+					col = col + thr * le;
+					new_ro = (ro + (rd * data.t)) + (PT_NORMAL_OFFSET * data.n);
+					v3 wm; float cos_theta, pdf;
+					const v3 wi = pick_wi(wo, mat, false, &wm, &cos_theta, &pdf, rng);
+					new_rd = normalize(mul(inverse_tnb, wi));
+					const v3 brdf = calc_brdf(sc, wo, wm, wi, mat, data.uvx, data.uvy, false);
+					thr = thr * ((cos_theta * brdf) / pdf);
+					const bool dead = thr.x == 0.0f && thr.y == 0.0f && thr.z == 0.0f && !(a.flags & PT_FLAG_TRACE_DEAD_PATHS);
+					if (last || dead) { accumulate(a, pid, col); alive = false; }
+					else emit_bounce = true;
+				} else {
+					const uint32_t num_ls = sc.n_light_tris + sc.n_light_spheres;
+					const float a2 = mat.d1.w * mat.d1.w;
+					const bool can_use_nee = num_ls > 0u && (mat.d2.w == 0.0f || mat.d2.w == 1.0f || (mat.d2.w == 2.0f && a2 > 0.0f));
+					if (mat.d2.w == -1.0f) {
+						if (a.stage == 0u || (meta & 8u)) col = col + thr * le; // fc:758-759
+						accumulate(a, pid, col);
+						alive = false;
+					} else {
+						if (can_use_nee) {
+							// fc:765-842 up to the shadow ray; the visibility-dependent part runs next stage
+							const float pdf_pick_light = 1.0f / (float) num_ls;
+							const LightPick L = sample_light(sc, num_ls, rng);
+							s_pdf = pdf_pick_light * (1.0f / L.area);
+							s_ro = (ro + rd * data.t) + PT_NORMAL_OFFSET * data.n;
+							const v3 dist_vec = L.y - s_ro;
+							s_rd = normalize(dist_vec);
+							const v3 wi = normalize(mul(tnb, s_rd));
+							const v3 wm = normalize(mul(tnb, data.n));
+							s_lb = L.le * calc_brdf(sc, wo, wm, wi, mat, data.uvx, data.uvy, true);
+							s_cos = fmax_(0.0f, dot(data.n, s_rd));
+							s_d2 = dot(dist_vec, dist_vec);
+							s_y = L.y;
+							thr_old = thr;
+							emit_shadow = true;
+						}
+						new_ro = ro + (rd * data.t + PT_NORMAL_OFFSET * data.n); // fc:848
+						v3 wm; float cos_theta_x, pdf;
+						const v3 wi = pick_wi(wo, mat, true, &wm, &cos_theta_x, &pdf, rng);
+						new_rd = normalize(mul(inverse_tnb, wi));
+						const v3 brdf = calc_brdf(sc, wo, wm, wi, mat, data.uvx, data.uvy, true);
+						new_meta = (emit_shadow ? 1u : 0u) | ((mat.d2.w == 2.0f && a2 <= 0.0f) ? 8u : 0u);
+						thr = thr * (brdf * cos_theta_x / pdf);
+						emit_bounce = !last;
+						if (last && !emit_shadow) { accumulate(a, pid, col); alive = false; }
+					}
+				}
+			}
+		}
+	}
+	if (!alive) { emit_bounce = false; emit_shadow = false; }
+	const uint32_t o = claim_slot(a, alive, emit_bounce, emit_shadow);
+	if (!alive) return;
+	a.out.pix[o] = pid;
+	a.out.rng[o] = rng;
+	a.out.meta[o] = new_meta;
+	st3(a.out.thr, o, st, thr);
+	st3(a.out.col, o, st, col);
+	st3(a.out.ray, o, st, new_ro);
+	st3(a.out.ray + 3 * (size_t) st, o, st, new_rd);
+	if (emit_shadow) {
+		st3(a.out.sray, o, st, s_ro);
+		st3(a.out.sray + 3 * (size_t) st, o, st, s_rd);
+		st3(a.out.nee, o, st, s_lb);
+		a.out.nee[3 * (size_t) st + o] = s_cos;
+		a.out.nee[4 * (size_t) st + o] = s_d2;
+		st3(a.out.nee + 5 * (size_t) st, o, st, s_y);
+		st3(a.out.bs, o, st, thr_old);
+		a.out.bs[3 * (size_t) st + o] = s_pdf;
+	}
 }
 
 // multi-GPU helpers: the packed order is the path order of k_raygen

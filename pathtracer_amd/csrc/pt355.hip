@@ -50,6 +50,7 @@ struct pt_ctx {
 	void *nodes_alloc = nullptr;
 	std::vector<void *> scene_allocs;
 	bool have_scene = false, have_camera = false;
+	uint32_t estimator = PT_EST_MIS;
 	float cam[12];
 
 	// queues
@@ -426,6 +427,7 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	memcpy(sa.cam, c->cam, sizeof sa.cam);
 	sa.width = c->cfg.width; sa.height = c->cfg.height;
 	sa.bounces = bounces;
+	sa.estimator = c->estimator;
 	sa.flags = c->cfg.flags;
 	sa.sample = pp.sample;
 	sa.fb = c->fb;
@@ -444,14 +446,33 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
 	end_timed(pp);
 	uint32_t qi = 0;
-	for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
-		int rc = launch_trace(c, pp, queue_trace_args(c, pp, qi, stage > 0));
-		if (rc) return rc;
-		sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
-		begin_timed(c, pp, 1);
-		hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, pp.stream, sa);
-		end_timed(pp);
-		qi ^= 1u;
+	if (c->estimator == PT_EST_MIS) {
+		for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
+			int rc = launch_trace(c, pp, queue_trace_args(c, pp, qi, stage > 0));
+			if (rc) return rc;
+			sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
+			begin_timed(c, pp, 1);
+			hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, pp.stream, sa);
+			end_timed(pp);
+			qi ^= 1u;
+		}
+	} else {
+		// fc:647-693 / fc:725-867: `bounces` intersect() calls per path; the NEE estimator's last shadow ray needs one
+		// more (shadow-only) trace and a resolve-only stage
+		const bool nee = c->estimator == PT_EST_NEE;
+		const uint32_t n_stages = sa.bounces ? sa.bounces + (nee ? 1u : 0u) : 0u;
+		for (uint32_t stage = 0; stage < n_stages; stage++) {
+			TraceArgs ta = queue_trace_args(c, pp, qi, nee && stage > 0);
+			ta.shadow_mode = PT_SHADOW_FULL; // this estimator's compare is two-sided (fc:821): no early-out rule built for it
+			if (nee && stage == sa.bounces) { ta.seg[0] = ta.seg[1]; ta.n_segs = 1; } // only shadow rays are left
+			int rc = launch_trace(c, pp, ta);
+			if (rc) return rc;
+			sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
+			begin_timed(c, pp, 1);
+			hipLaunchKernelGGL(k_shade_alt, sgrid, sblock, 0, pp.stream, sa);
+			end_timed(pp);
+			qi ^= 1u;
+		}
 	}
 	// the running mean is order-dependent: this batch is blended after the previous one, whichever pipeline ran it
 	if (c->last_resolved >= 0 && (uint32_t) c->last_resolved != pi)
@@ -471,6 +492,14 @@ static int image_touched(pt_ctx *c)
 {
 	HIP_TRY(c, hipEventRecord(c->pipe[0].resolved, c->stream));
 	c->last_resolved = 0;
+	return PT_OK;
+}
+
+int pt_set_estimator(pt_ctx *c, uint32_t estimator)
+{
+	if (!c) return PT_EINVAL;
+	if (estimator > PT_EST_BRDF) return fail(c, PT_EINVAL, "pt_set_estimator: unknown estimator %u", estimator);
+	c->estimator = estimator;
 	return PT_OK;
 }
 

@@ -15,6 +15,8 @@ REF_SO = os.path.join(ROOT, "oracle", "_ref", "libptref.so")
 
 OP = dict(MIN=0, MAX=1, DIV=2, SQRT=3, F2H2F=4, SIN=5, COS=6, TAN=7, ACOS=8, ATAN2=9, HADD=10, HMUL=11, RAND=12, OREN_NAYAR=13, GGX_NEE=14, GGX_IS=15)
 FLAG_LIBM = 1
+FLAG_EST_NEE = 2
+FLAG_EST_BRDF = 4
 
 
 class oracle_scene(ctypes.Structure):

@@ -194,3 +194,21 @@ def test_libm_variant_is_statistically_the_same_image(pt, ol):
     same = (a.view(np.uint32) == b.view(np.uint32)).all(axis=2).mean()
     rel = np.abs(a[..., :3].mean() - b[..., :3].mean()) / a[..., :3].mean()
     assert same > 0.2 and rel < 0.02, (same, rel)
+
+
+def test_alternative_estimators_oracle_sanity(pt, ol):
+    """NEE-only and MIS estimate the same radiance (same path depth); BRDF-only is one segment shorter, hence darker in
+    a closed box, and with a single bounce it sees only directly visible emitters."""
+    sc = pt.Scene.cornell()
+    osc, cam, seeds = ol.scene_from_desc(sc.desc()), pt.default_camera(), pt.frame_seeds(0, 48)
+    mis, _ = ol.render(osc, cam, 48, 48, seeds)
+    nee, cn = ol.render(osc, cam, 48, 48, seeds, flags=ol.FLAG_EST_NEE)
+    brdf, cb = ol.render(osc, cam, 48, 48, seeds, flags=ol.FLAG_EST_BRDF)
+    m = float(mis[..., :3].mean())
+    assert abs(float(nee[..., :3].mean()) - m) < 0.03 * m
+    assert 0.5 * m < float(brdf[..., :3].mean()) < m
+    assert cb["rays_shadow"] == 0 and cn["rays_shadow"] > 0
+    one, c1 = ol.render(osc, cam, 48, 48, seeds[:1], bounces=1, flags=ol.FLAG_EST_BRDF)
+    assert c1["rays_bounce"] == 0 and np.unique(one[..., :3].reshape(-1, 3), axis=0).shape[0] == 2
+    zero, c0 = ol.render(osc, cam, 48, 48, seeds[:1], bounces=0, flags=ol.FLAG_EST_NEE)
+    assert c0["rays_primary"] == 0 and not zero[..., :3].any()
