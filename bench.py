@@ -64,6 +64,10 @@ def main():
     ap.add_argument("--trace-dead-paths", action="store_true", help="trace zero-throughput paths like the reference does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; what the driver runs) or gloo (rehearsal of the N > 1 "
+                    "code path with several ranks sharing one GPU: the reduce then goes through host memory)")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the reduced image with a sequential render of the same "
+                    "N*K global frames on rank 0 (tolerance 2e-6 relative)")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,8 +82,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        local_rank %= max(torch.cuda.device_count(), 1)  # rehearsal: more ranks than GPUs share a device
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     if not torch.cuda.is_available():
@@ -109,7 +117,12 @@ def main():
         # finished framebuffer -> rank 0: pack (tile order), weight, RCCL sum-reduce, unpack on rank 0
         ctx.pack_owned(red.data_ptr())
         ctx.sync()
-        mg.reduce_samples(dist, red, n_local, n_total)
+        if args.dist_backend == "nccl":
+            mg.reduce_samples(dist, red, n_local, n_total)
+        else:
+            host = red.cpu()
+            mg.reduce_samples(dist, host, n_local, n_total)
+            red.copy_(host)
         if rank == 0:
             torch.cuda.synchronize()
             ctx.unpack_from(red.data_ptr(), 0, 1)
@@ -141,6 +154,19 @@ def main():
         rays_total, paths_total = int(tot[0].item()), int(tot[1].item())
     else:
         rays_total, paths_total = rays, cnt["paths"]
+
+    check = None
+    if dist is not None and args.check and rank == 0:
+        got = ctx.read_framebuffer()
+        sctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, max_batch=args.max_batch)
+        sctx.upload_scene(scene)
+        sctx.set_camera(cam)
+        timed = np.concatenate([seeds[r::world][args.warmup:] for r in range(world)])  # the frames of the timed region
+        sctx.render(0, timed, args.bounces)
+        seq = sctx.read_framebuffer()
+        sctx.close()
+        err = np.abs(got[..., :3] - seq[..., :3]) / np.maximum(np.abs(seq[..., :3]), 1e-3)
+        check = {"max_rel_err_vs_sequential": float(err.max()), "ok": bool(err.max() < 2e-6)}
 
     if rank != 0:
         ctx.close()
@@ -207,6 +233,8 @@ def main():
         "rays": {"primary": cnt["rays_primary"], "shadow": cnt["rays_shadow"], "bounce": cnt["rays_bounce"], "scope": "rank0" if world > 1 else "all"},
         "stack_spills": cnt["stack_spills"], "roofline": roofline, "cpu_baseline": cpu,
     }
+    if check is not None:
+        out["check"] = check
     print(json.dumps(out))
     ctx.close()
     if dist is not None:
