@@ -8,7 +8,9 @@
 //  * traversal stack: PT_SHORT_STACK entries per lane in LDS, laid out [level][lane] so that a
 //    wave-wide push/pop is bank-conflict free whatever the per-lane depth; deeper pushes spill to a
 //    per-wave HBM tail (counted in pt_counters.stack_spills; the reference has 16 slots and no check);
-//  * node pairs are siblings: 64 contiguous, 64-byte aligned bytes -> 4 x dwordx4 per lane per step;
+//  * the kernel walks its own copy of the BVH, built at upload ("traversal blob", below): one 64-byte record per
+//    inner node with both children's bounds and integer links, and 64-byte triangle records with the edges already
+//    subtracted -> 4 x dwordx4 per lane per step from ONE base pointer with 32-bit offsets;
 //    the packed normals / material of a triangle are only used by the shading kernel for the one accepted hit;
 //  * arithmetic order follows the shader exactly -- the hit index is part of the bit-exact contract.
 #pragma once
@@ -28,8 +30,15 @@
 #define PT_SHARD_STRIDE 32   // u32 words between two counters = 128 bytes
 
 struct DevScene {
-	const float4 *nodes;   // node i at nodes[2*i]; allocation is shifted so pairs (2k+1, 2k+2) are 64-B aligned
-	const float4 *tris;    // triangle i at tris[4*i]
+	// Traversal blob (pt355.hip build_traversal_blob), addressed by 32-bit byte offsets:
+	//   record of an inner node, 64 B: (lo0.xyz, link0) (hi0.xyz, bytes0) (lo1.xyz, link1) (hi1.xyz, bytes1) -- the bounds of
+	//     its two children as uploaded; bytesK = 64 * triangle count of child K (0 = inner); linkK = offset of the child's
+	//     own record, or of its first triangle record.  The record of node 0 (the pair 1, 2) is at offset 0.
+	//   triangle record, 64 B: (v0.xyz, index) (e1.xyz, -) (e2.xyz, -) (-): the triangles of a left leaf are followed by
+	//     those of its right sibling, so the two hit leaves of one step are ONE pending range.
+	const char *tblob;
+	uint32_t n_records;    // inner nodes; 0 = nothing to traverse (a root that is a leaf)
+	const float4 *tris;    // triangle i at tris[4*i] (shading)
 	const float4 *mats;    // material i at mats[3*i]
 	const float4 *spheres; // sphere i at spheres[2*i]
 	const uint32_t *light_tris;
@@ -109,7 +118,7 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 	return -1.0f;
 }
 
-#define PT_CUR_DONE 0xfffffffeu
+#define PT_CUR_DONE 0xffffffffu
 
 // Shadow rays (fc:970-974) are judged by the shading kernel from the CLOSEST hit: the light sample is visible iff
 // every component of y_nee - (ro + rd * t_hit) is < 0.01 (one-sided).
@@ -135,16 +144,18 @@ PT_DEV float shadow_kill_component(float y, float ro, float rd)
 }
 
 // Per-lane state machine.  A lane is in one of two modes each iteration:
-//   N  fetch the sibling pair at `cur`, run both slab tests, queue the triangles of the hit leaves as a pending
-//      range [tri_i, tri_end) and pick the next `cur` (descend / push / pop) -- one iteration of while(true), fc:352-418,
-//      minus its triangle loop;
+//   N  fetch the record at `cur` (the two children of an inner node), run both slab tests, make the triangles of the
+//      hit leaves the pending range [tri, tri_end) and pick the next `cur` (descend / push / pop) -- one iteration of
+//      while(true), fc:352-418, minus its triangle loop;
 //   T  test ONE pending triangle (fc:368-378).
 // Both modes fetch 64 aligned bytes through the same four dwordx4 loads, so a wave iteration costs ONE memory round
 // trip whatever mix of modes its lanes are in, and every active lane makes progress every iteration.  (The first
 // version ran the triangle loop inside the node step: a lane with an 8-triangle leaf held 63 others through 8
 // dependent round trips -- VALU lane utilisation 24 %, profiles/r01b.)  The order of operations seen by ONE ray is
 // unchanged: the pending triangles are tested, in order, before the next pair's slab tests read tmax, and the
-// descend/push/pop decision never depended on them (the stack holds node indices only).
+// descend/push/pop decision never depended on them (the stack holds record offsets only).
+// cur, tri, tri_end and the stack entries are byte offsets into the traversal blob: the address of either mode is
+// one select away, and no index is converted or range-checked here (pt_upload_scene proved every link).
 template <bool COUNT>
 __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 {
@@ -155,16 +166,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 
 	if (blockIdx.x == 0 && threadIdx.x < PT_SHARDS && a.zero_on_entry) a.zero_on_entry[threadIdx.x * PT_SHARD_STRIDE] = 0;
 
-	const float4 *__restrict__ nodes = a.sc.nodes;
-	const float4 *__restrict__ tris = a.sc.tris;
-	const uint32_t n_nodes = a.sc.n_nodes, n_tris_total = a.sc.n_tris;
+	const char *__restrict__ blob = a.sc.tblob;
+	const bool have_tree = a.sc.n_records != 0u;
 
 	// per-lane ray state
 	bool active = false;
 	uint32_t slot = 0;
 	v3 ro = V(0, 0, 0), rd = V(0, 0, 0), inv = V(0, 0, 0);
 	float tmax = PT_TMAX;
-	uint32_t cur = PT_CUR_DONE, sp = 0, tri_i = 0, tri_end = 0;
+	uint32_t cur = PT_CUR_DONE, sp = 0, tri = 0, tri_end = 0;
 	uint32_t best_prim = 0xffffffffu, best_tk = 0;
 	float best_u = 0.0f, best_v = 0.0f;
 	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
@@ -264,13 +274,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 						rd = q16(frd);
 						inv = V(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z); // fc:347
 						tmax = PT_TMAX;
-						sp = 0; tri_i = 0; tri_end = 0;
+						sp = 0; tri = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
 						if (occluded_now) {
 							if (a.shadow_mode == PT_SHADOW_ANYHIT) sph_tk = (sph_tk & 0xffffu) | (3u << 16);
 							a.seg[lane_seg].hit[slot] = make_uint4(sph_prim, sph_tk, 0u, 0u);
-						} else if (n_nodes >= 3u) { cur = 1u; active = true; }
+						} else if (have_tree) { cur = 0u; active = true; }
 						else a.seg[lane_seg].hit[slot] = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
 					}
 				}
@@ -283,13 +293,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 
 		// ------------------------------------------------------------------ traverse until enough lanes go idle
 		for (;;) {
-			// every active lane has work: pending triangles (T) or a node pair to visit (N); lanes retire at once
-			const bool tmode = active && tri_i < tri_end;
+			// every active lane has work: pending triangles (T) or a record to visit (N); lanes retire at once
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
-			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form: the kernel is
-			// bound by dependent round trips, not by VALU issue -- DESIGN.md "What was tried".)
+			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form -- DESIGN.md
+			// "What was tried".)
 			if (active) {
-				const float4 *p = tmode ? tris + 4u * (size_t) tri_i : nodes + 2u * (size_t) cur;
+				const bool tmode = tri < tri_end;
+				const float4 *p = (const float4 *) (blob + (tmode ? tri : cur));
 				float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
 				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
@@ -297,9 +307,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 				if (tmode) {
 					// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
 					if (COUNT) n_tests++;
+					tri += 64u;
 					const v3 v0 = V(q0.x, q0.y, q0.z);
-					const v3 e1 = V(q1.x, q1.y, q1.z) - v0;
-					const v3 e2 = V(q2.x, q2.y, q2.z) - v0;
+					const v3 e1 = V(q1.x, q1.y, q1.z);
+					const v3 e2 = V(q2.x, q2.y, q2.z);
 					const v3 pv = cross(rd, e2);
 					const float det = dot(e1, pv);
 					const float inv_det = 1.0f / det;
@@ -312,56 +323,53 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 						if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
 							const h16 th = to_h16(t);
 							tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
-							best_prim = tri_i;
+							best_prim = __float_as_uint(q0.w);
 							best_tk = h_bits(th) | (1u << 16);
 							best_u = u; best_v = v;
 							if (tmax <= t_kill) { // shadow ray decided: nothing closer can change the verdict
-								tri_i = tri_end - 1u; cur = PT_CUR_DONE; sph_tk = 0u;
+								tri = tri_end; cur = PT_CUR_DONE; sph_tk = 0u;
 								if (a.shadow_mode == PT_SHADOW_ANYHIT) best_tk = (best_tk & 0xffffu) | (3u << 16);
 							}
 						}
 					}
-					tri_i++;
 				} else {
 					if (COUNT) n_steps++;
 					float le, lx, re, rx;
 					box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
 					box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
 					const bool in_l = le <= lx, in_r = re <= rx;
-					const bool leaf_l = q1.w > 0.0f, leaf_r = q3.w > 0.0f;
-					const uint32_t c_l = (uint32_t) q0.w, c_r = (uint32_t) q2.w; // first child, or first triangle of a leaf
-					// fc:364-382: triangles of the hit leaves become the pending range
-					const uint32_t n_leaf = (in_l ? (uint32_t) q1.w : 0u) + (in_r ? (uint32_t) q3.w : 0u);
-					const uint32_t t_first = (in_l && leaf_l) ? c_l : c_r;
-					uint32_t t_end = t_first + n_leaf;
-					t_end = t_end < n_tris_total ? t_end : n_tris_total; // foreign BVH whose sibling leaves are not contiguous
-					tri_i = n_leaf ? (t_first < t_end ? t_first : t_end) : tri_i;
-					tri_end = n_leaf ? t_end : tri_end;
+					const uint32_t c_l = __float_as_uint(q0.w), c_r = __float_as_uint(q2.w); // child record, or first triangle of a leaf
+					const uint32_t b_l = __float_as_uint(q1.w), b_r = __float_as_uint(q3.w); // 64 * triangles of a leaf, 0 = inner
+					const bool leaf_l = b_l != 0u, leaf_r = b_r != 0u;
+					// fc:364-382: the triangles of the hit leaves become the pending range (empty when no leaf was hit;
+					// a lane in N mode has none pending, so nothing is overwritten)
+					tri = (in_l && leaf_l) ? c_l : c_r;
+					tri_end = tri + ((in_l ? b_l : 0u) + (in_r ? b_r : 0u));
 					// fc:384-418, as selects: descend into the nearer hit inner child, push the farther, else pop
 					const bool go_l = in_l && !leaf_l, go_r = in_r && !leaf_r;
 					const bool both = go_l && go_r, any = go_l || go_r;
 					const bool r_first = le > re; // tie -> left first
 					const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
-					uint32_t next = both ? nearer : (go_l ? c_l : c_r);
+					cur = both ? nearer : (go_l ? c_l : c_r);
 					if (both) {
-						if (sp < PT_SHORT_STACK) lds[sp * 64u] = farther;
-						else if (sp < PT_SHORT_STACK + PT_SPILL_STACK) { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; }
+						if (__builtin_expect(sp < PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
+						else { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; } // sp < 64: pt_upload_scene bounds the depth
 						sp++;
 					}
 					if (!any) {
-						next = PT_CUR_DONE;
+						cur = PT_CUR_DONE;
 						if (sp != 0u) {
 							sp--;
-							next = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
-							if (sp >= PT_SHORT_STACK) next = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
+							cur = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
+							if (__builtin_expect(sp >= PT_SHORT_STACK, 0)) cur = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
 						}
 					}
-					cur = (next != PT_CUR_DONE && next + 1u >= n_nodes) ? PT_CUR_DONE : next; // corrupt index: stop rather than fault
 				}
-				if (tri_i >= tri_end && cur == PT_CUR_DONE) {
+				if (tri >= tri_end && cur == PT_CUR_DONE) {
 					// retire: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax)
 					if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
-					a.seg[lane_seg].hit[slot] = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
+					uint4 *const hits = lane_seg ? a.seg[1].hit : a.seg[0].hit;
+					hits[slot] = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
 					active = false;
 				}
 			}

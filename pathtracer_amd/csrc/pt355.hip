@@ -325,6 +325,85 @@ int pt_destroy(pt_ctx *c)
 	return PT_OK;
 }
 
+// The traversal's own copy of the BVH (kernels_trace.h "Traversal blob"): one 64-byte record per INNER node holding
+// its two children (bounds as uploaded, links and triangle counts as integers in bytes), then 64-byte triangle
+// records (v0, e1 = v1 - v0, e2 = v2 - v0 -- the same fp32 subtractions fc:273-274 performs -- and the triangle's
+// index) in the order the records reference them: the triangles of a left leaf, then those of its right sibling.
+// Also proves what the kernel relies on: every link lands inside the blob and every node has at most one parent
+// (so the walk from the root is a tree walk and ends).
+static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<uint32_t> &blob, uint32_t *n_records)
+{
+	const float *nd = (const float *) s->nodes;
+	const float *tr = (const float *) s->tris;
+	const uint32_t n = s->n_nodes;
+	std::vector<uint32_t> rec_of(n, 0xffffffffu);
+	uint32_t n_inner = 0;
+	uint64_t n_ttris = 0;
+	std::vector<uint8_t> claimed(n, 0);
+	// the shader starts at node 1 whatever node 0 says (fc:343-350): node 0 is "inner with children 1, 2" when there are any
+	auto inner = [&](uint32_t i) { return i == 0 ? n >= 3u : !(nd[8 * i + 7] > 0.0f); };
+	auto child = [&](uint32_t i) { return i == 0 ? 1u : (uint32_t) nd[8 * i + 3]; };
+	for (uint32_t i = 0; i < n; i++) {
+		if (!inner(i)) continue;
+		rec_of[i] = n_inner++;
+		const uint32_t ch = child(i);
+		for (uint32_t k = 0; k < 2; k++) {
+			if (claimed[ch + k]) return fail(c, PT_EINVAL, "pt_upload_scene: node %u is the child of two nodes (not a tree)", ch + k);
+			claimed[ch + k] = 1;
+			if (nd[8 * (ch + k) + 7] > 0.0f) n_ttris += (uint64_t) nd[8 * (ch + k) + 7];
+		}
+	}
+	// the traversal stack holds one entry per level below the root: 16 in LDS + 48 spilled = the builder's max_depth
+	if (n_inner) {
+		std::vector<std::pair<uint32_t, uint32_t>> walk{{0u, 1u}};
+		while (!walk.empty()) {
+			const auto [i, depth] = walk.back();
+			walk.pop_back();
+			if (depth > PT_SHORT_STACK + PT_SPILL_STACK)
+				return fail(c, PT_EINVAL, "pt_upload_scene: BVH deeper than %d levels (the traversal stack's size)", PT_SHORT_STACK + PT_SPILL_STACK);
+			for (uint32_t k = 0; k < 2; k++)
+				if (inner(child(i) + k)) walk.push_back({child(i) + k, depth + 1u});
+		}
+	}
+	const uint64_t bytes = ((uint64_t) n_inner + n_ttris) * 64u;
+	if (bytes >= 0xffffff00ull) return fail(c, PT_EINVAL, "pt_upload_scene: traversal data of %llu bytes exceeds the 32-bit offsets of the trace kernel", (unsigned long long) bytes);
+	blob.assign((size_t) (bytes / 4u), 0u);
+	uint32_t tcur = n_inner * 64u; // byte offset of the next triangle record
+	auto f2u = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+	for (uint32_t i = 0; i < n; i++) {
+		if (rec_of[i] == 0xffffffffu) continue;
+		uint32_t *r = &blob[(size_t) rec_of[i] * 16u];
+		const uint32_t ch = child(i);
+		for (uint32_t k = 0; k < 2; k++) {
+			const float *cn = nd + 8 * (size_t) (ch + k);
+			uint32_t *o = r + 8 * k;
+			o[0] = f2u(cn[0]); o[1] = f2u(cn[1]); o[2] = f2u(cn[2]);
+			o[4] = f2u(cn[4]); o[5] = f2u(cn[5]); o[6] = f2u(cn[6]);
+			const uint32_t cnt = cn[7] > 0.0f ? (uint32_t) cn[7] : 0u;
+			if (cnt == 0u) {
+				o[3] = rec_of[ch + k] * 64u; // an inner child always has a record (n > 1 here)
+				o[7] = 0u;
+			} else {
+				o[3] = tcur;
+				o[7] = cnt * 64u;
+				const uint32_t first = (uint32_t) cn[3];
+				for (uint32_t t = first; t < first + cnt; t++, tcur += 64u) {
+					const float *src = tr + 16 * (size_t) t;
+					uint32_t *d = &blob[tcur / 4u];
+					const float v0[3] = {src[0], src[1], src[2]};
+					for (int a = 0; a < 3; a++) {
+						const float e1 = src[4 + a] - v0[a], e2 = src[8 + a] - v0[a];
+						d[a] = f2u(v0[a]); d[4 + a] = f2u(e1); d[8 + a] = f2u(e2);
+					}
+					d[3] = t;
+				}
+			}
+		}
+	}
+	*n_records = n_inner;
+	return PT_OK;
+}
+
 int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 {
 	if (!c || !s) return PT_EINVAL;
@@ -364,11 +443,13 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 	DevScene d;
 	memset(&d, 0, sizeof d);
 	int rc;
-	// 32 bytes of front padding put node 1 (and with it every sibling pair) on a 64-byte boundary
-	char *nodes = nullptr;
-	if ((rc = upload(c, s->nodes, (size_t) s->n_nodes * 32, &nodes, 32 + 64))) return rc;
-	// hipMalloc is 256-B aligned; (32+64) keeps node 0 at offset 96, node 1 at 128
-	d.nodes = (const float4 *) nodes;
+	std::vector<uint32_t> blob;
+	uint32_t n_records = 0;
+	if ((rc = build_traversal_blob(c, s, blob, &n_records))) return rc;
+	char *tb = nullptr;
+	if ((rc = upload(c, blob.data(), blob.size() * 4, &tb))) return rc; // hipMalloc is 256-B aligned: records sit on 64-B lines
+	d.tblob = tb;
+	d.n_records = n_records;
 	char *tmp = nullptr;
 	if ((rc = upload(c, s->tris, (size_t) s->n_tris * 64, &tmp))) return rc;
 	d.tris = (const float4 *) tmp;
