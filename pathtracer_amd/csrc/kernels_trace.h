@@ -171,7 +171,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 
 	// per-lane ray state
 	bool active = false;
-	uint32_t slot = 0;
+	uint4 *hitp = nullptr;
 	v3 ro = V(0, 0, 0), rd = V(0, 0, 0), inv = V(0, 0, 0);
 	float tmax = PT_TMAX;
 	uint32_t cur = PT_CUR_DONE, sp = 0, tri = 0, tri_end = 0;
@@ -182,10 +182,51 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	uint32_t n_steps = 0, n_tests = 0, n_spills = 0;
 	// wave-uniform work state
 	bool exhausted = false;
-	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0, lane_seg = 0; // the unit this wave is handing out to its lanes
+	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0; // the unit this wave is handing out to its lanes
 	uint32_t shard = (blockIdx.x * PT_TRACE_WAVES + wave) % PT_SHARDS, shards_done = 0;
 	uint32_t shard_count = 0, shard_units = 0;
 	bool shard_known = false;
+
+	// One N step on the record (q0..q3) for this lane's ray: fc:352-418 minus the triangle loop (see k_trace's header).
+	auto node_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
+		if (COUNT) n_steps++;
+		float le, lx, re, rx;
+		box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
+		box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
+		const bool in_l = le <= lx, in_r = re <= rx;
+		const uint32_t c_l = __float_as_uint(q0.w), c_r = __float_as_uint(q2.w); // child record, or first triangle of a leaf
+		const uint32_t b_l = __float_as_uint(q1.w), b_r = __float_as_uint(q3.w); // 64 * triangles of a leaf, 0 = inner
+		const bool leaf_l = b_l != 0u, leaf_r = b_r != 0u;
+		// fc:364-382: the triangles of the hit leaves become the pending range (empty when no leaf was hit;
+		// a lane in N mode has none pending, so nothing is overwritten)
+		tri = (in_l && leaf_l) ? c_l : c_r;
+		tri_end = tri + ((in_l ? b_l : 0u) + (in_r ? b_r : 0u));
+		// fc:384-418, as selects: descend into the nearer hit inner child, push the farther, else pop
+		const bool go_l = in_l && !leaf_l, go_r = in_r && !leaf_r;
+		const bool both = go_l && go_r, any = go_l || go_r;
+		const bool r_first = le > re; // tie -> left first
+		const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
+		cur = both ? nearer : (go_l ? c_l : c_r);
+		if (both) {
+			if (__builtin_expect(sp < PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
+			else { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; } // sp < 64: pt_upload_scene bounds the depth
+			sp++;
+		}
+		if (!any) {
+			cur = PT_CUR_DONE;
+			if (sp != 0u) {
+				sp--;
+				cur = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
+				if (__builtin_expect(sp >= PT_SHORT_STACK, 0)) cur = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
+			}
+		}
+	};
+	// Retire the lane's ray: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax).
+	auto retire = [&]() {
+		if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
+		*hitp = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
+		active = false;
+	};
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill idle lanes
@@ -230,9 +271,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 			if (!active) {
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
 				if (rank < take) {
-					slot = base + rank;
-					lane_seg = loc_seg;
+					const uint32_t slot = base + rank;
 					const RaySeg &rs = a.seg[loc_seg];
+					hitp = rs.hit + slot; // where this ray's record goes: kept per lane so that retiring is a store, not a load of the segment table first
 					bool ok = rs.valid ? (rs.valid[slot] & 1u) != 0 : true;
 					if (ok) {
 						const float *r = rs.ray + slot;
@@ -279,9 +320,11 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 						// a root that is a leaf has no children to start from: spheres only
 						if (occluded_now) {
 							if (a.shadow_mode == PT_SHADOW_ANYHIT) sph_tk = (sph_tk & 0xffffu) | (3u << 16);
-							a.seg[lane_seg].hit[slot] = make_uint4(sph_prim, sph_tk, 0u, 0u);
-						} else if (have_tree) { cur = 0u; active = true; }
-						else a.seg[lane_seg].hit[slot] = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
+							*hitp = make_uint4(sph_prim, sph_tk, 0u, 0u);
+						} else if (have_tree) {
+							cur = 0u; active = true;
+						}
+						else *hitp = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
 					}
 				}
 			}
@@ -332,46 +375,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 							}
 						}
 					}
-				} else {
-					if (COUNT) n_steps++;
-					float le, lx, re, rx;
-					box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
-					box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
-					const bool in_l = le <= lx, in_r = re <= rx;
-					const uint32_t c_l = __float_as_uint(q0.w), c_r = __float_as_uint(q2.w); // child record, or first triangle of a leaf
-					const uint32_t b_l = __float_as_uint(q1.w), b_r = __float_as_uint(q3.w); // 64 * triangles of a leaf, 0 = inner
-					const bool leaf_l = b_l != 0u, leaf_r = b_r != 0u;
-					// fc:364-382: the triangles of the hit leaves become the pending range (empty when no leaf was hit;
-					// a lane in N mode has none pending, so nothing is overwritten)
-					tri = (in_l && leaf_l) ? c_l : c_r;
-					tri_end = tri + ((in_l ? b_l : 0u) + (in_r ? b_r : 0u));
-					// fc:384-418, as selects: descend into the nearer hit inner child, push the farther, else pop
-					const bool go_l = in_l && !leaf_l, go_r = in_r && !leaf_r;
-					const bool both = go_l && go_r, any = go_l || go_r;
-					const bool r_first = le > re; // tie -> left first
-					const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
-					cur = both ? nearer : (go_l ? c_l : c_r);
-					if (both) {
-						if (__builtin_expect(sp < PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
-						else { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; } // sp < 64: pt_upload_scene bounds the depth
-						sp++;
-					}
-					if (!any) {
-						cur = PT_CUR_DONE;
-						if (sp != 0u) {
-							sp--;
-							cur = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
-							if (__builtin_expect(sp >= PT_SHORT_STACK, 0)) cur = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
-						}
-					}
-				}
-				if (tri >= tri_end && cur == PT_CUR_DONE) {
-					// retire: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax)
-					if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
-					uint4 *const hits = lane_seg ? a.seg[1].hit : a.seg[0].hit;
-					hits[slot] = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
-					active = false;
-				}
+				} else node_step(q0, q1, q2, q3);
+				if (tri >= tri_end && cur == PT_CUR_DONE) retire();
 			}
 			const unsigned long long act = __ballot(active);
 			if (act == 0ull) break;
