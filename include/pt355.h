@@ -163,6 +163,20 @@ int pt_unpack_from(pt_ctx *ctx, const void *src_dev, uint32_t from_rank, uint32_
  * (op codes as in oracle/oracle.h) so tests can pin device min/max/div/sqrt/fp16/transcendentals. */
 int pt_debug_eval(pt_ctx *ctx, int op, const float *a, const float *b, uint32_t n, float *out);
 
+/* ---- BVH build on the GPU.  The reference builds on one CPU thread (CalculateBVH, src/scene/bvh.cpp:31-75,
+ * rebuilt bit for bit as pth_build_bvh); this is the same step for scenes where that build dominates the set-up: a
+ * linear BVH (Morton order, radix tree, bottom-up bounds; subtrees of <= max_leaf triangles become leaves, max_leaf
+ * 1..16, 0 = 2) built on ctx's device and returned in the reference's own layout -- same arguments and output
+ * contract as pth_build_bvh: tris = n packed 64-byte triangles in any order, nodes_out = room for 2n+1 32-byte nodes,
+ * sorted_out = n triangles in leaf order.  The tree differs from the Sweep-SAH tree (the bit-exactness contract covers
+ * the CPU builder); it is a valid input of pt_upload_scene, the oracle and the reference's shader.  build_ms
+ * (optional) receives the device time of the build proper. */
+int pt_build_bvh_device(pt_ctx *ctx, const void *tris, uint32_t n, uint32_t max_leaf, void *nodes_out, uint32_t *n_nodes_out,
+                        void *sorted_out, float *build_ms);
+/* pth_scene_finalize (pt355_host.h) with that builder in place of CalculateBVH */
+struct pth_scene;
+int pt_scene_finalize_device(pt_ctx *ctx, struct pth_scene *scene, uint32_t max_leaf, float *build_ms);
+
 /* Debug read-back of one column group of a path queue (queue 0/1; field: 0 pix, 1 rng, 2 meta, 3 thr, 4 col,
  * 5 ray, 6 shadow ray, 7 nee, 8 bsdf, 9 hit, 10 shadow hit).  n_words = columns * stride.  No reference counterpart. */
 int pt_debug_read_queue(pt_ctx *ctx, uint32_t queue, uint32_t field, void *out, size_t n_words, uint32_t *stride, uint32_t *count);

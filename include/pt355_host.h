@@ -63,6 +63,11 @@ int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const 
                             uint32_t count);
 /* Model::ConvertToSSBOFormat + CalculateBVH + FindEmissive* (src/main.cpp:31-55) */
 int pth_scene_finalize(pth_scene *s);
+/* Same, with the BVH built by `build` instead of CalculateBVH: build(tris, n, nodes_out [2n+1 nodes of room],
+ * sorted_out [n triangles], user) returns the node count, 0 on failure.  pt_scene_finalize_device (pt355.h) passes
+ * the GPU builder. */
+typedef uint32_t (*pth_bvh_builder)(const void *tris, uint32_t n, void *nodes_out, void *sorted_out, void *user);
+int pth_scene_finalize_with(pth_scene *s, pth_bvh_builder build, void *user);
 /* pointers stay valid until the next mutation / destroy */
 int pth_scene_desc(const pth_scene *s, pt_scene_desc *out);
 uint64_t pth_scene_hash(const pth_scene *s); /* FNV-1a over the six arrays, binding order */

@@ -80,6 +80,8 @@ EXPORTS = {
     "pt_unpack_from": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32]),
     "pt_debug_eval": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_uint32, c_void_p]),
     "pt_debug_read_queue": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32)]),
+    "pt_build_bvh_device": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p, POINTER(c_uint32), c_void_p, POINTER(c_float)]),
+    "pt_scene_finalize_device": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_float)]),
     # host side
     "pth_pack_half2x16": (c_uint32, [c_float, c_float]),
     "pth_oct_encode": (None, [c_void_p, c_void_p]),
@@ -97,6 +99,7 @@ EXPORTS = {
     "pth_scene_add_sphere": (c_int, [c_void_p, c_void_p, c_float, c_uint32]),
     "pth_scene_add_triangles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     "pth_scene_finalize": (c_int, [c_void_p]),
+    "pth_scene_finalize_with": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pth_scene_desc": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
     "pth_scene_hash": (c_uint64, [c_void_p]),
     "pth_scene_make_cornell": (c_int, [c_void_p, c_uint32]),
@@ -344,6 +347,23 @@ class PathTracer:
 
     def unpack_from(self, src_ptr: int, from_rank: int, world: int):
         self._check(lib().pt_unpack_from(self._h, c_void_p(src_ptr), from_rank, world), "pt_unpack_from")
+
+    def build_bvh_device(self, tris, max_leaf: int = 4):
+        """GPU LBVH over n packed 64-byte triangles (u32 [n,16]); returns (nodes u32 [m,8], sorted tris u32 [n,16], build ms)."""
+        tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 16)
+        n = tris.shape[0]
+        nodes = np.zeros((2 * n + 1, 8), np.uint32)
+        out = np.zeros_like(tris)
+        nn, ms = c_uint32(), c_float()
+        self._check(lib().pt_build_bvh_device(self._h, _ptr(tris), n, max_leaf, _ptr(nodes), byref(nn), _ptr(out), byref(ms)),
+                    "pt_build_bvh_device")
+        return nodes[: nn.value].copy(), out, ms.value
+
+    def finalize_scene_device(self, scene: "Scene", max_leaf: int = 4) -> float:
+        """Re-finalizes `scene` with the GPU builder in place of CalculateBVH; returns the build's device ms."""
+        ms = c_float()
+        self._check(lib().pt_scene_finalize_device(self._h, scene._h, max_leaf, byref(ms)), "pt_scene_finalize_device")
+        return ms.value
 
     def debug_read_queue(self, queue: int, field: int) -> np.ndarray:
         cols = [1, 1, 1, 3, 3, 6, 6, 8, 5, 4, 4][field]

@@ -186,8 +186,16 @@ int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const 
 	return PT_OK;
 }
 
-int pth_scene_finalize(pth_scene *s)
+static uint32_t reference_builder(const void *tris, uint32_t n, void *nodes_out, void *sorted_out, void *)
 {
+	return pth_build_bvh(tris, n, nodes_out, sorted_out);
+}
+
+int pth_scene_finalize(pth_scene *s) { return pth_scene_finalize_with(s, reference_builder, nullptr); }
+
+int pth_scene_finalize_with(pth_scene *s, pth_bvh_builder build, void *user)
+{
+	if (!s || !build) return PT_EINVAL;
 	const size_t n = s->mat.size();
 	if (n == 0) return PT_EINVAL;
 	for (size_t i = 0; i < n; i++)
@@ -199,7 +207,7 @@ int pth_scene_finalize(pth_scene *s)
 		pth_pack_triangle(&s->v[9 * i], &s->uv[6 * i], &s->n[9 * i], s->mat[i], &unsorted[i]);
 	s->tris.resize(n);
 	s->nodes.resize(2 * n + 1);
-	uint32_t nn = pth_build_bvh(unsorted.data(), (uint32_t) n, s->nodes.data(), s->tris.data());
+	uint32_t nn = build(unsorted.data(), (uint32_t) n, s->nodes.data(), s->tris.data(), user);
 	if (nn == 0) return PT_EINVAL;
 	s->nodes.resize(nn);
 	s->light_tris.resize(n);

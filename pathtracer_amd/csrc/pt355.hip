@@ -14,7 +14,9 @@
 #include <vector>
 
 #include "../../include/pt355.h"
+#include "../../include/pt355_host.h"
 #include "kernels_shade.h"
+#include "bvh_device.h"
 
 namespace {
 
@@ -817,6 +819,34 @@ int pt_debug_read_queue(pt_ctx *c, uint32_t queue, uint32_t field, void *out, si
 	if (stride) *stride = c->stride;
 	if (count) { *count = 0; for (uint32_t r = 0; r < PT_SHARDS; r++) *count += qc[r * PT_SHARD_STRIDE]; }
 	return PT_OK;
+}
+
+int pt_build_bvh_device(pt_ctx *c, const void *tris, uint32_t n, uint32_t max_leaf, void *nodes_out, uint32_t *n_nodes_out,
+                        void *sorted_out, float *build_ms)
+{
+	if (!c) return PT_EINVAL;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	char err[256] = "";
+	const int rc = ptb_build_lbvh(c->stream, tris, n, max_leaf ? max_leaf : 2u, nodes_out, n_nodes_out, sorted_out, build_ms, err, sizeof err);
+	if (rc) return fail(c, rc == 1 ? PT_EINVAL : PT_EHIP, "%s", err);
+	return PT_OK;
+}
+
+static uint32_t scene_builder_thunk(const void *tris, uint32_t n, void *nodes_out, void *sorted_out, void *user)
+{
+	void **u = (void **) user;
+	uint32_t nn = 0;
+	const int rc = pt_build_bvh_device((pt_ctx *) u[0], tris, n, (uint32_t) (uintptr_t) u[1], nodes_out, &nn, sorted_out, (float *) u[2]);
+	return rc == PT_OK ? nn : 0u;
+}
+
+int pt_scene_finalize_device(pt_ctx *c, pth_scene *s, uint32_t max_leaf, float *build_ms)
+{
+	if (!c || !s) return PT_EINVAL;
+	void *user[3] = {c, (void *) (uintptr_t) max_leaf, build_ms};
+	const int rc = pth_scene_finalize_with(s, scene_builder_thunk, user);
+	if (rc != PT_OK && c->err.empty()) return fail(c, rc, "pt_scene_finalize_device: the scene could not be finalized");
+	return rc;
 }
 
 int pt_debug_eval(pt_ctx *c, int op, const float *a, const float *b, uint32_t n, float *out)
