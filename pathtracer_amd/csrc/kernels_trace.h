@@ -34,8 +34,9 @@ struct DevScene {
 	//   record of an inner node, 64 B: (lo0.xyz, link0) (hi0.xyz, bytes0) (lo1.xyz, link1) (hi1.xyz, bytes1) -- the bounds of
 	//     its two children as uploaded; bytesK = 64 * triangle count of child K (0 = inner); linkK = offset of the child's
 	//     own record, or of its first triangle record.  The record of node 0 (the pair 1, 2) is at offset 0.
-	//   triangle record, 64 B: (v0.xyz, index) (e1.xyz, -) (e2.xyz, -) (-): the triangles of a left leaf are followed by
-	//     those of its right sibling, so the two hit leaves of one step are ONE pending range.
+	//   triangle record, 64 B: (v0.xyz, index) (e1.xyz, -) (e2.xyz, -) (-), laid out as the shader's merged leaf loop walks
+	//     them (fc:356-368, quirk 5): a left leaf's n_l triangles are followed by the next n_r triangles of the array, so
+	//     the two hit leaves of one step are ONE pending range.
 	const char *tblob;
 	uint32_t n_records;    // inner nodes; 0 = nothing to traverse (a root that is a leaf)
 	const float4 *tris;    // triangle i at tris[4*i] (shading)

@@ -340,7 +340,6 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 	const uint32_t n = s->n_nodes;
 	std::vector<uint32_t> rec_of(n, 0xffffffffu);
 	uint32_t n_inner = 0;
-	uint64_t n_ttris = 0;
 	std::vector<uint8_t> claimed(n, 0);
 	// the shader starts at node 1 whatever node 0 says (fc:343-350): node 0 is "inner with children 1, 2" when there are any
 	auto inner = [&](uint32_t i) { return i == 0 ? n >= 3u : !(nd[8 * i + 7] > 0.0f); };
@@ -352,7 +351,6 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 		for (uint32_t k = 0; k < 2; k++) {
 			if (claimed[ch + k]) return fail(c, PT_EINVAL, "pt_upload_scene: node %u is the child of two nodes (not a tree)", ch + k);
 			claimed[ch + k] = 1;
-			if (nd[8 * (ch + k) + 7] > 0.0f) n_ttris += (uint64_t) nd[8 * (ch + k) + 7];
 		}
 	}
 	// the traversal stack holds one entry per level below the root: 16 in LDS + 48 spilled = the builder's max_depth
@@ -367,41 +365,60 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 				if (inner(child(i) + k)) walk.push_back({child(i) + k, depth + 1u});
 		}
 	}
-	const uint64_t bytes = ((uint64_t) n_inner + n_ttris) * 64u;
-	if (bytes >= 0xffffff00ull) return fail(c, PT_EINVAL, "pt_upload_scene: traversal data of %llu bytes exceeds the 32-bit offsets of the trace kernel", (unsigned long long) bytes);
-	blob.assign((size_t) (bytes / 4u), 0u);
-	uint32_t tcur = n_inner * 64u; // byte offset of the next triangle record
+	// triangle records, in the order the shader's merged leaf loop walks them (fc:356-368): when the left
+	// child is a leaf the loop starts at ITS first triangle and runs over n_left + n_right consecutive triangles of the
+	// array -- the right leaf's own triangles only if the builder laid the two ranges out back to back, as the
+	// reference's does.  A foreign tree that did not gets exactly what the shader would do with it: the run after the
+	// left leaf (entries past the end of the array are never-hit records: the shader's loop reads out of bounds there),
+	// and the right leaf's own range as a second copy for the steps that hit only the right leaf.
+	std::vector<uint32_t> tt;
+	tt.reserve((size_t) s->n_tris * 16u);
 	auto f2u = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+	auto emit_range = [&](uint32_t first, uint32_t count) {
+		const uint64_t off = (uint64_t) n_inner * 64u + (uint64_t) tt.size() * 4u;
+		for (uint64_t t = first; t < (uint64_t) first + count; t++) {
+			uint32_t d[16] = {0};
+			d[3] = 0xffffffffu;
+			if (t < s->n_tris) {
+				const float *src = tr + 16 * (size_t) t;
+				const float v0[3] = {src[0], src[1], src[2]};
+				for (int a = 0; a < 3; a++) {
+					const float e1 = src[4 + a] - v0[a], e2 = src[8 + a] - v0[a];
+					d[a] = f2u(v0[a]); d[4 + a] = f2u(e1); d[8 + a] = f2u(e2);
+				}
+				d[3] = (uint32_t) t;
+			}
+			tt.insert(tt.end(), d, d + 16);
+		}
+		return off;
+	};
+	blob.assign((size_t) n_inner * 16u, 0u);
 	for (uint32_t i = 0; i < n; i++) {
 		if (rec_of[i] == 0xffffffffu) continue;
-		uint32_t *r = &blob[(size_t) rec_of[i] * 16u];
 		const uint32_t ch = child(i);
+		uint32_t cnt[2], first[2];
+		uint64_t link[2] = {0, 0};
+		for (uint32_t k = 0; k < 2; k++) {
+			const float *cn = nd + 8 * (size_t) (ch + k);
+			cnt[k] = cn[7] > 0.0f ? (uint32_t) cn[7] : 0u;
+			first[k] = (uint32_t) cn[3];
+			if (cnt[k] == 0u) link[k] = (uint64_t) rec_of[ch + k] * 64u; // an inner child always has a record
+		}
+		if (cnt[0]) {
+			link[0] = emit_range(first[0], cnt[0] + cnt[1]);
+			if (cnt[1]) link[1] = first[1] == first[0] + cnt[0] ? link[0] + (uint64_t) cnt[0] * 64u : emit_range(first[1], cnt[1]);
+		} else if (cnt[1]) link[1] = emit_range(first[1], cnt[1]);
+		if ((uint64_t) n_inner * 64u + (uint64_t) tt.size() * 4u >= 0xffffff00ull)
+			return fail(c, PT_EINVAL, "pt_upload_scene: traversal data exceeds the 32-bit offsets of the trace kernel");
+		uint32_t *r = &blob[(size_t) rec_of[i] * 16u];
 		for (uint32_t k = 0; k < 2; k++) {
 			const float *cn = nd + 8 * (size_t) (ch + k);
 			uint32_t *o = r + 8 * k;
-			o[0] = f2u(cn[0]); o[1] = f2u(cn[1]); o[2] = f2u(cn[2]);
-			o[4] = f2u(cn[4]); o[5] = f2u(cn[5]); o[6] = f2u(cn[6]);
-			const uint32_t cnt = cn[7] > 0.0f ? (uint32_t) cn[7] : 0u;
-			if (cnt == 0u) {
-				o[3] = rec_of[ch + k] * 64u; // an inner child always has a record (n > 1 here)
-				o[7] = 0u;
-			} else {
-				o[3] = tcur;
-				o[7] = cnt * 64u;
-				const uint32_t first = (uint32_t) cn[3];
-				for (uint32_t t = first; t < first + cnt; t++, tcur += 64u) {
-					const float *src = tr + 16 * (size_t) t;
-					uint32_t *d = &blob[tcur / 4u];
-					const float v0[3] = {src[0], src[1], src[2]};
-					for (int a = 0; a < 3; a++) {
-						const float e1 = src[4 + a] - v0[a], e2 = src[8 + a] - v0[a];
-						d[a] = f2u(v0[a]); d[4 + a] = f2u(e1); d[8 + a] = f2u(e2);
-					}
-					d[3] = t;
-				}
-			}
+			o[0] = f2u(cn[0]); o[1] = f2u(cn[1]); o[2] = f2u(cn[2]); o[3] = (uint32_t) link[k];
+			o[4] = f2u(cn[4]); o[5] = f2u(cn[5]); o[6] = f2u(cn[6]); o[7] = cnt[k] * 64u;
 		}
 	}
+	blob.insert(blob.end(), tt.begin(), tt.end());
 	*n_records = n_inner;
 	return PT_OK;
 }

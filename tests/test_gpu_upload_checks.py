@@ -1,0 +1,119 @@
+"""pt_upload_scene must turn a malformed scene into an error code -- never into a GPU fault or an endless traversal
+(INTEGRATION.md "Error behaviour").  Also: a foreign BVH whose sibling leaves are not contiguous in the triangle
+array is traversed like the shader traverses it (left leaf's triangles, then the right leaf's)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _desc_from(pt, arrays, **override):
+    a = dict(arrays)
+    a.update(override)
+    d = pt.pt_scene_desc()
+    keep = []
+    for field, count, key in (("spheres", "n_spheres", "spheres"), ("tris", "n_tris", "tris"), ("light_tris", "n_light_tris", "light_tris"),
+                              ("materials", "n_materials", "materials"), ("nodes", "n_nodes", "nodes"),
+                              ("light_spheres", "n_light_spheres", "light_spheres")):
+        arr = np.ascontiguousarray(a[key], np.uint32)
+        keep.append(arr)
+        setattr(d, field, arr.ctypes.data if arr.size else None)
+        setattr(d, count, arr.shape[0])
+    d._keep = keep
+    return d
+
+
+def _upload_fails(pt, d, needle):
+    c = pt.PathTracer(8, 8)
+    try:
+        with pytest.raises(pt.PtError) as e:
+            c.upload_scene(d)
+        assert needle in str(e.value), str(e.value)
+    finally:
+        c.close()
+
+
+def test_malformed_scenes_are_error_codes(pt):
+    base = pt.Scene.soup(200, seed=4).arrays()
+    nodes = base["nodes"].copy()
+    nf = nodes.view(np.float32)
+    inner = [i for i in range(1, nodes.shape[0]) if nf[i, 7] == 0.0]
+    leaf = [i for i in range(1, nodes.shape[0]) if nf[i, 7] > 0.0]
+
+    bad = nodes.copy(); bad.view(np.float32)[inner[0], 3] = float(nodes.shape[0] + 10)          # child outside the array
+    _upload_fails(pt, _desc_from(pt, base, nodes=bad), "outside the array")
+
+    bad = nodes.copy(); bad.view(np.float32)[leaf[0], 3] = float(base["tris"].shape[0] - 1); bad.view(np.float32)[leaf[0], 7] = 5.0
+    _upload_fails(pt, _desc_from(pt, base, nodes=bad), "runs past the triangle array")
+
+    bad = nodes.copy(); bad.view(np.float32)[inner[1], 3] = nf[inner[0], 3]                       # two parents for one pair: a DAG / cycle
+    _upload_fails(pt, _desc_from(pt, base, nodes=bad), "not a tree")
+
+    bad = nodes.copy(); bad.view(np.float32)[inner[0], 3] = 1.0                                   # points back at the root pair: a cycle
+    _upload_fails(pt, _desc_from(pt, base, nodes=bad), "not a tree")
+
+    bad = nodes.copy(); bad.view(np.float32)[inner[0], 3] = np.nan
+    _upload_fails(pt, _desc_from(pt, base, nodes=bad), "negative/NaN")
+
+    tris = base["tris"].copy(); tris[3, 15] = 99
+    _upload_fails(pt, _desc_from(pt, base, tris=tris), "uses material")
+
+    _upload_fails(pt, _desc_from(pt, base, nodes=nodes[:-1]), "odd node count")
+    _upload_fails(pt, _desc_from(pt, base, light_tris=np.array([10 ** 6], np.uint32)), "light triangle index")
+
+
+def test_a_chain_deeper_than_the_stack_is_refused(pt):
+    """A degenerate 70-level chain (every right child a one-triangle leaf) is beyond the 64-entry traversal stack."""
+    base = pt.Scene.soup(80, seed=4).arrays()
+    tris = base["tris"]
+    levels = 70
+    nodes = np.zeros((2 * levels + 1, 8), np.float32)
+    lo, hi = np.float32(-10.0), np.float32(10.0)
+    nodes[:, 0:3] = lo; nodes[:, 4:7] = hi
+    nodes[0, 3] = 1.0
+    for k in range(levels):
+        l, r = 1 + 2 * k, 2 + 2 * k
+        if k + 1 < levels:
+            nodes[l, 3] = 1 + 2 * (k + 1); nodes[l, 7] = 0.0
+        else:
+            nodes[l, 3] = 0.0; nodes[l, 7] = 1.0
+        nodes[r, 3] = 1 + (k % 70); nodes[r, 7] = 1.0
+    _upload_fails(pt, _desc_from(pt, base, nodes=nodes.view(np.uint32), tris=tris), "deeper than")
+
+
+def test_non_contiguous_sibling_leaves(pt, ol):
+    """Foreign BVH: the two leaves of one pair point at triangle ranges that are far apart in the array."""
+    base = pt.Scene.soup(64, seed=6, size=0.8).arrays()
+    tris = base["tris"]
+    v = tris.view(np.float32)[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3, 3)
+
+    def box(ids):
+        return v[ids].reshape(-1, 3).min(0), v[ids].reshape(-1, 3).max(0)
+
+    groups = [list(range(0, 16)), list(range(48, 64)), list(range(16, 32)), list(range(32, 48))]  # leaf ranges: 0-15, 48-63 | 16-31, 32-47
+    nodes = np.zeros((7, 8), np.float32)
+    alllo, allhi = box(list(range(64)))
+    nodes[0, 0:3], nodes[0, 4:7], nodes[0, 3] = alllo, allhi, 1.0
+    for k, (a, b) in enumerate(((0, 1), (2, 3))):
+        lo, hi = box(groups[a] + groups[b])
+        nodes[1 + k, 0:3], nodes[1 + k, 4:7], nodes[1 + k, 3], nodes[1 + k, 7] = lo, hi, 3 + 2 * k, 0.0
+        for j, g in enumerate((a, b)):
+            glo, ghi = box(groups[g])
+            i = 3 + 2 * k + j
+            nodes[i, 0:3], nodes[i, 4:7], nodes[i, 3], nodes[i, 7] = glo, ghi, float(groups[g][0]), 16.0
+    d = _desc_from(pt, base, nodes=nodes.view(np.uint32), light_tris=np.zeros(0, np.uint32))
+    rng = np.random.default_rng(2)
+    n = 50000
+    ro = np.stack([rng.uniform(-1.9, 1.9, n), rng.uniform(-1.9, 1.9, n), rng.uniform(-7.9, -4.1, n)], 1).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    c = pt.PathTracer(8, 8)
+    try:
+        c.upload_scene(d)
+        prim, th, kind, uv = c.trace_closest(ro, rd)
+    finally:
+        c.close()
+    oprim, oth, okind, ouv = ol.trace_closest(ol.scene_from_desc(d), ro, rd)
+    assert (kind == 1).mean() > 0.2
+    assert np.array_equal(kind, okind) and np.array_equal(prim, oprim) and np.array_equal(th, oth)
+    assert np.array_equal(uv.view(np.uint32), ouv.view(np.uint32))
