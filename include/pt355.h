@@ -57,7 +57,8 @@ typedef struct pt_config {
 	uint32_t flags;
 	uint32_t partition;    /* PT_PARTITION_* */
 	uint32_t rank, world;  /* this context's share; world = 0 or 1 means the whole image */
-	uint32_t max_batch;    /* frames pt_render traces together (1..32); 0 = default (16, less for very large images).
+	uint32_t max_batch;    /* frames pt_render traces together (1..32); 0 = default (32, less for images above 2 Mpixel:
+	                          at most 2^26 paths = ~23 GB of queues are in flight).
 	                          Results do not depend on it: samples are blended into the image in frame order. */
 	uint32_t pipelines;    /* independent frame pipelines (streams + queues) batches alternate between (1..4); 0 = default (1).
 	                          Results do not depend on it either. */

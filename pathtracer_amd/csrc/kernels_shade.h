@@ -12,6 +12,9 @@
 #include "kernels_trace.h"
 
 #define PT_SHADE_BLOCK 256
+#ifndef PT_SHADE_MIN_BLOCKS
+#define PT_SHADE_MIN_BLOCKS 7 // 72 VGPRs -> 7 waves/SIMD: 1.7 % faster than the 75 VGPRs / 6 waves the compiler picks alone; 8 (64 VGPRs) spills
+#endif
 #define PT_EST_MIS 0u   // estimator_path_tracing_mis,  fc:874-1081 (the live one, fc:1111)
 #define PT_EST_NEE 1u   // estimator_path_tracing_nee,  fc:725-867
 #define PT_EST_BRDF 2u  // estimator_path_tracing_BRDF, fc:647-693
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_resolve(ShadeArgs a)
 
 // One shading stage.  stage 0 consumes the primary hit (fc:880-896); stage k >= 1 consumes the shadow and
 // bounce hits of bounce k (fc:970-1077) and, unless k == bounces, emits bounce k+1 (fc:901-968, 1009-1017).
-__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade(ShadeArgs a)
+__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(ShadeArgs a)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t in_region = blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size

@@ -45,7 +45,7 @@ struct pt_ctx {
 	std::string err;
 	int n_cu = 0;
 	int trace_grid = 0;
-	uint32_t refill_threshold = 24;
+	uint32_t refill_threshold = 32; // idle lanes that trigger a refill: sweep 8..64 on the bench scene peaks at 32 (a refill costs ~3 loop iterations)
 
 	// scene
 	DevScene sc{};
@@ -271,8 +271,9 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	c->n_paths = own_tiles(cfg->width, cfg->height, cfg->partition, cfg->rank, world) * 64u;
 	// Frames in flight per set of launches.  A trace launch costs ~0.25 ms of ramp-up and tail whatever its size
 	// (DESIGN.md "Batching"), so a batch is made as large as a modest memory budget allows: <= 2^26 paths (~23 GB of
-	// the 288 GB).  Measured at 1080p: 8 -> 6.89, 16 -> 7.24, 32 -> 7.40 Grays/s.
-	c->max_batch = cfg->max_batch ? cfg->max_batch : 16u;
+	// the 288 GB).  Measured at 1080p: 8 -> 6.89, 16 -> 7.24, 32 -> 7.40 Grays/s (r01e kernel); 16 -> 8.39, 24 -> 8.51,
+	// 32 -> 8.59 (r01g kernel).
+	c->max_batch = cfg->max_batch ? cfg->max_batch : (uint32_t) PT_MAX_BATCH;
 	if (c->max_batch > PT_MAX_BATCH) c->max_batch = PT_MAX_BATCH;
 	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 26)) c->max_batch--;
 	if (const char *e = getenv("PT355_BATCH")) { int v = atoi(e); if (v >= 1 && v <= PT_MAX_BATCH) c->max_batch = (uint32_t) v; }

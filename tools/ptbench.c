@@ -1,8 +1,8 @@
 /* ptbench -- minimal native driver of libpt355.so for profiling runs (rocprofv3 wants the program itself after
  * "--", and a PMC pass should not pay a Python start-up).  Renders the bench.py workload: bunny-class scene,
  * 1920x1080, MIS, 5 bounces.   usage: ptbench [frames] [width] [height] [scene: 0 bunny ON, 1 bunny GGX, 2 cornell] [flags]
- * The warm-up is one full default batch (16 frames), so that every launch a profiler sees has the size of the timed
- * ones and its per-kernel averages are those of the timed region. */
+ * The warm-up is one full batch (pt_get_info: frames per launch set), so that every launch a profiler sees has the size
+ * of the timed ones (give a multiple of the batch as `frames`) and its per-kernel averages are those of the timed region. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -38,7 +38,9 @@ int main(int argc, char **argv)
 	float cam[12];
 	pth_pack_camera(o, f, r, 0.005f, 0.05f, cam);
 	pt_set_camera(c, cam);
-	const uint32_t warm = 16;
+	uint32_t info[8] = {0};
+	pt_get_info(c, info);
+	const uint32_t warm = info[0] ? info[0] : 16;
 	uint32_t *seeds = (uint32_t *) malloc(sizeof(uint32_t) * (frames + warm));
 	pth_frame_seeds(0, frames + warm, seeds);
 	if (pt_render(c, 0, warm, seeds, 5) || pt_sync(c)) { fprintf(stderr, "render: %s\n", pt_last_error(c)); return 1; }
