@@ -215,6 +215,11 @@ struct Scratch {
 	}
 };
 
+struct Events {
+	hipEvent_t e[2] = {nullptr, nullptr};
+	~Events() { for (hipEvent_t x : e) if (x) (void) hipEventDestroy(x); }
+};
+
 } // namespace
 
 #define B_TRY(call)                                                                                     \
@@ -249,8 +254,9 @@ int ptb_build_lbvh(hipStream_t stream, const void *tris_host, uint32_t n, uint32
 	B_TRY(s.get(&d_nodes, (size_t) (2u * ni + 1u) * sizeof(NodeOut)));
 
 	B_TRY(hipMemcpyAsync(d_tris, tris_host, (size_t) n * 64, hipMemcpyHostToDevice, stream));
-	hipEvent_t e0, e1;
-	B_TRY(hipEventCreate(&e0)); B_TRY(hipEventCreate(&e1));
+	Events ev;
+	B_TRY(hipEventCreate(&ev.e[0])); B_TRY(hipEventCreate(&ev.e[1]));
+	const hipEvent_t e0 = ev.e[0], e1 = ev.e[1];
 	B_TRY(hipEventRecord(e0, stream));
 	const int big = 0x7fffffff;
 	const int init[6] = {big, big, big, -big - 1, -big - 1, -big - 1};
@@ -292,7 +298,6 @@ int ptb_build_lbvh(hipStream_t stream, const void *tris_host, uint32_t n, uint32
 	B_TRY(hipStreamSynchronize(stream));
 	float ms = 0.0f;
 	B_TRY(hipEventElapsedTime(&ms, e0, e1));
-	(void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
 	if (build_ms) *build_ms = ms;
 	*n_nodes_out = n_nodes;
 	return 0;
