@@ -6,6 +6,8 @@
 // (they queue on the same vector-memory pipeline) and the frame time does not improve.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -106,6 +108,33 @@ uint32_t host_path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_
 	const uint32_t in = p & 63u;
 	return ((tile / tiles_x) * 8u + (in >> 3)) * width + (tile % tiles_x) * 8u + (in & 7u);
 }
+
+// Profiler ranges around the host-side phases, the counterpart of the reference's glPushDebugGroup("COMPUTE")
+// (src/main.cpp:78).  roctx is looked up at run time so that the library carries no link dependency on a profiler
+// component; without it (or without a tool attached) a range is two null checks.  rocprofv3 --marker-trace shows them.
+struct Range {
+	typedef int (*push_fn)(const char *);
+	typedef int (*pop_fn)(void);
+	static push_fn &push() { static push_fn f = nullptr; return f; }
+	static pop_fn &pop() { static pop_fn f = nullptr; return f; }
+	static void resolve()
+	{
+		static bool done = false;
+		if (done) return;
+		done = true;
+		for (const char *name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4"}) {
+			if (void *h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
+				push() = (push_fn) dlsym(h, "roctxRangePushA");
+				pop() = (pop_fn) dlsym(h, "roctxRangePop");
+				if (push() && pop()) return;
+				push() = nullptr; pop() = nullptr;
+			}
+		}
+	}
+	bool open = false;
+	explicit Range(const char *name) { resolve(); if (push()) { push()(name); open = true; } }
+	~Range() { if (open && pop()) pop()(); }
+};
 
 void begin_timed(pt_ctx *c, Pipe &pp, int kind)
 {
@@ -427,6 +456,7 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 {
 	if (!c || !s) return PT_EINVAL;
+	Range range("pt355 upload_scene");
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	if (!s->tris || s->n_tris == 0 || !s->nodes || s->n_nodes == 0 || !s->materials || s->n_materials == 0)
 		return fail(c, PT_EINVAL, "pt_upload_scene: triangles, nodes and materials must be non-empty");
@@ -512,6 +542,9 @@ int pt_set_camera(pt_ctx *c, const float cam[12])
 static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const uint32_t *seeds, uint32_t bounces)
 {
 	if (c->n_paths == 0) { c->frames += n_batch; return PT_OK; }
+	char range_name[64];
+	snprintf(range_name, sizeof range_name, "pt355 batch: frames %u..%u", first_frame, first_frame + n_batch - 1u);
+	Range range(range_name);
 	const uint32_t pi = c->next_pipe;
 	Pipe &pp = c->pipe[pi];
 	c->next_pipe = (pi + 1u) % c->n_pipes;
@@ -843,6 +876,7 @@ int pt_build_bvh_device(pt_ctx *c, const void *tris, uint32_t n, uint32_t max_le
                         void *sorted_out, float *build_ms)
 {
 	if (!c) return PT_EINVAL;
+	Range range("pt355 build_bvh_device");
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	char err[256] = "";
 	const int rc = ptb_build_lbvh(c->stream, tris, n, max_leaf ? max_leaf : 2u, nodes_out, n_nodes_out, sorted_out, build_ms, err, sizeof err);
