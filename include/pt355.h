@@ -78,6 +78,11 @@ typedef struct pt_scene_desc {
 	const uint32_t *light_spheres;  uint32_t n_light_spheres;
 	const uint8_t  *env_rgb8;       uint32_t env_w, env_h;   /* NULL: texture without storage -> black */
 	const uint8_t  *tex_rgb8;       uint32_t tex_layers;     /* 512 x 512 x layers, RGB8 */
+	/* sampler state of the texture array: the GL enums the loader takes from the glTF sampler and sets array-wide
+	 * (src/loader.cpp:242-251).  0 = the loader's defaults GL_REPEAT (10497) / GL_LINEAR (9729); also understood:
+	 * GL_CLAMP_TO_EDGE 33071, GL_MIRRORED_REPEAT 33648, GL_NEAREST 9728.  The minification filter never applies: a compute
+	 * shader's texture() samples level 0. */
+	uint32_t tex_wrap_s, tex_wrap_t, tex_mag_filter;
 } pt_scene_desc;
 
 /* Rays are counted when they are enqueued to a trace kernel. */

@@ -214,6 +214,7 @@ struct Scene {
 	const uint32_t *light_spheres; uint32_t n_light_spheres;
 	const uint8_t *env; uint32_t env_w, env_h;
 	const uint8_t *tex; uint32_t tex_layers;
+	uint32_t tex_wrap_s, tex_wrap_t, tex_mag_filter;
 };
 Scene view(const oracle_scene *s)
 {
@@ -226,6 +227,7 @@ Scene view(const oracle_scene *s)
 	v.light_spheres = s->light_spheres; v.n_light_spheres = s->n_light_spheres;
 	v.env = s->env_rgb8; v.env_w = s->env_w; v.env_h = s->env_h;
 	v.tex = s->tex_rgb8; v.tex_layers = s->tex_layers;
+	v.tex_wrap_s = s->tex_wrap_s; v.tex_wrap_t = s->tex_wrap_t; v.tex_mag_filter = s->tex_mag_filter;
 	return v;
 }
 
@@ -615,24 +617,38 @@ v3 pick_wi(const Fn &fn, v3 wo, const Mat &mat, bool using_NEE, v3 *wm, float *c
 	return V(INFINITY, INFINITY, INFINITY);
 }
 
-// sampler2DArray lookup, 512x512 RGB8, GL_REPEAT + GL_LINEAR at mip 0 (loader.cpp:50-58 defaults)
+// sampler2DArray lookup, 512x512 RGB8 at mip 0 (texture() in a compute shader: lod 0, magnification filter); wrap modes
+// and filter are the array-wide sampler state of loader.cpp:242-251 (defaults GL_REPEAT / GL_LINEAR, loader.cpp:50-58)
 v3 sample_texture(const Scene &sc, float u, float v, float layer)
 {
 	if (!sc.tex || sc.tex_layers == 0) return V(0, 0, 0);
 	int l = (int) floorf(layer + 0.5f);
 	l = l < 0 ? 0 : (l >= (int) sc.tex_layers ? (int) sc.tex_layers - 1 : l);
 	const uint8_t *img = sc.tex + (size_t) l * 512 * 512 * 3;
-	float x = u * 512.0f - 0.5f, y = v * 512.0f - 0.5f;
-	float fx = floorf(x), fy = floorf(y);
-	float ax = x - fx, ay = y - fy;
-	int x0 = ((int) fx % 512 + 512) % 512, y0 = ((int) fy % 512 + 512) % 512;
-	int x1 = (x0 + 1) % 512, y1 = (y0 + 1) % 512;
+	// OpenGL 4.6 section 8.14.2, table 8.21: wrap(i) per mode; 0 = the loader's defaults GL_REPEAT / GL_LINEAR
+	auto wrap = [](int i, uint32_t mode) {
+		if (mode == 33071u) return i < 0 ? 0 : (i > 511 ? 511 : i);               // GL_CLAMP_TO_EDGE
+		if (mode == 33648u) {                                                       // GL_MIRRORED_REPEAT
+			int a = ((i % 1024) + 1024) % 1024 - 512;
+			a = a >= 0 ? a : -(1 + a);
+			return 511 - a;
+		}
+		return ((i % 512) + 512) % 512;                                             // GL_REPEAT
+	};
 	auto tx = [&](int xx, int yy) {
 		const uint8_t *p = img + ((size_t) yy * 512 + (size_t) xx) * 3;
 		return V((float) p[0] / 255.0f, (float) p[1] / 255.0f, (float) p[2] / 255.0f);
 	};
-	v3 top = tx(x0, y0) * (1.0f - ax) + tx(x1, y0) * ax;
-	v3 bot = tx(x0, y1) * (1.0f - ax) + tx(x1, y1) * ax;
+	if (sc.tex_mag_filter == 9728u) {                                               // GL_NEAREST
+		return tx(wrap((int) floorf(u * 512.0f), sc.tex_wrap_s), wrap((int) floorf(v * 512.0f), sc.tex_wrap_t));
+	}
+	const float x = u * 512.0f - 0.5f, y = v * 512.0f - 0.5f;
+	const float fx = floorf(x), fy = floorf(y);
+	const float ax = x - fx, ay = y - fy;
+	const int x0 = wrap((int) fx, sc.tex_wrap_s), y0 = wrap((int) fy, sc.tex_wrap_t);
+	const int x1 = wrap((int) fx + 1, sc.tex_wrap_s), y1 = wrap((int) fy + 1, sc.tex_wrap_t);
+	const v3 top = tx(x0, y0) * (1.0f - ax) + tx(x1, y0) * ax;
+	const v3 bot = tx(x0, y1) * (1.0f - ax) + tx(x1, y1) * ax;
 	return top * (1.0f - ay) + bot * ay;
 }
 

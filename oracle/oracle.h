@@ -28,6 +28,7 @@ typedef struct oracle_scene {
 	const uint32_t *light_spheres; uint32_t n_light_spheres; /* binding 5 */
 	const uint8_t *env_rgb8;    uint32_t env_w, env_h;     /* sampler unit 1 (NULL: no storage -> black) */
 	const uint8_t *tex_rgb8;    uint32_t tex_layers;       /* sampler unit 2, 512x512xN RGB8 (NULL: none) */
+	uint32_t tex_wrap_s, tex_wrap_t, tex_mag_filter;       /* GL enums of loader.cpp:242-251; 0 = GL_REPEAT / GL_LINEAR */
 } oracle_scene;
 
 typedef struct oracle_counters {

@@ -42,7 +42,8 @@ class pt_scene_desc(ctypes.Structure):
                 ("nodes", c_void_p), ("n_nodes", c_uint32),
                 ("light_spheres", c_void_p), ("n_light_spheres", c_uint32),
                 ("env_rgb8", c_void_p), ("env_w", c_uint32), ("env_h", c_uint32),
-                ("tex_rgb8", c_void_p), ("tex_layers", c_uint32)]
+                ("tex_rgb8", c_void_p), ("tex_layers", c_uint32),
+                ("tex_wrap_s", c_uint32), ("tex_wrap_t", c_uint32), ("tex_mag_filter", c_uint32)]
 
 
 class pt_counters(ctypes.Structure):
@@ -136,6 +137,9 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+GL_REPEAT, GL_CLAMP_TO_EDGE, GL_MIRRORED_REPEAT, GL_NEAREST, GL_LINEAR = 10497, 33071, 33648, 9728, 9729
 
 
 def _ptr(a):
@@ -270,8 +274,12 @@ class PathTracer:
     def __del__(self):
         self.close()
 
-    def upload_scene(self, scene, env_rgb8: np.ndarray | None = None, tex_rgb8: np.ndarray | None = None):
+    def upload_scene(self, scene, env_rgb8: np.ndarray | None = None, tex_rgb8: np.ndarray | None = None,
+                     tex_sampler: tuple | None = None):
+        """tex_sampler = (wrap_s, wrap_t, mag_filter) as GL enums (GL_REPEAT ... below); None = the loader's defaults."""
         d = scene.desc() if isinstance(scene, Scene) else scene
+        if tex_sampler is not None:
+            d.tex_wrap_s, d.tex_wrap_t, d.tex_mag_filter = tex_sampler
         keep = [scene]
         if env_rgb8 is not None:
             env = np.ascontiguousarray(env_rgb8, np.uint8)

@@ -182,22 +182,37 @@ PT_DEV v3 sky_color(const DevScene &sc, v3 dir)
 	return q16(top * (1.0f - ay) + bot * ay);
 }
 
-// sampler2DArray, 512x512 RGB8, GL_REPEAT + GL_LINEAR, level 0 (src/loader.cpp:50-58)
+// sampler2DArray, 512x512 RGB8, level 0 (a compute shader's texture() has no derivatives: lod 0, the magnification
+// filter applies).  Wrap modes and filter are the array-wide sampler state the loader sets from the glTF sampler
+// (src/loader.cpp:242-251; defaults GL_REPEAT / GL_LINEAR, src/loader.cpp:50-58).
 PT_DEV v3 sample_texture(const DevScene &sc, float u, float v, float layer)
 {
 	if (!sc.tex || sc.tex_layers == 0) return V(0.0f, 0.0f, 0.0f);
 	int l = (int) __builtin_floorf(layer + 0.5f);
 	l = l < 0 ? 0 : (l >= (int) sc.tex_layers ? (int) sc.tex_layers - 1 : l);
 	const uint8_t *img = sc.tex + (size_t) l * 512 * 512 * 3;
-	const float x = u * 512.0f - 0.5f, y = v * 512.0f - 0.5f;
-	const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
-	const float ax = x - fx, ay = y - fy;
-	const int x0 = ((int) fx % 512 + 512) % 512, y0 = ((int) fy % 512 + 512) % 512;
-	const int x1 = (x0 + 1) % 512, y1 = (y0 + 1) % 512;
+	// OpenGL 4.6 section 8.14.2, table 8.21: wrap(i) per mode; 0 = the loader's defaults GL_REPEAT / GL_LINEAR
+	auto wrap = [](int i, uint32_t mode) {
+		if (mode == 33071u) return i < 0 ? 0 : (i > 511 ? 511 : i);               // GL_CLAMP_TO_EDGE
+		if (mode == 33648u) {                                                       // GL_MIRRORED_REPEAT
+			int a = ((i % 1024) + 1024) % 1024 - 512;
+			a = a >= 0 ? a : -(1 + a);
+			return 511 - a;
+		}
+		return ((i % 512) + 512) % 512;                                             // GL_REPEAT
+	};
 	auto tx = [&](int xx, int yy) {
 		const uint8_t *p = img + ((size_t) yy * 512 + (size_t) xx) * 3;
 		return V((float) p[0] / 255.0f, (float) p[1] / 255.0f, (float) p[2] / 255.0f);
 	};
+	if (sc.tex_mag_filter == 9728u) {                                               // GL_NEAREST
+		return tx(wrap((int) __builtin_floorf(u * 512.0f), sc.tex_wrap_s), wrap((int) __builtin_floorf(v * 512.0f), sc.tex_wrap_t));
+	}
+	const float x = u * 512.0f - 0.5f, y = v * 512.0f - 0.5f;
+	const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+	const float ax = x - fx, ay = y - fy;
+	const int x0 = wrap((int) fx, sc.tex_wrap_s), y0 = wrap((int) fy, sc.tex_wrap_t);
+	const int x1 = wrap((int) fx + 1, sc.tex_wrap_s), y1 = wrap((int) fy + 1, sc.tex_wrap_t);
 	const v3 top = tx(x0, y0) * (1.0f - ax) + tx(x1, y0) * ax;
 	const v3 bot = tx(x0, y1) * (1.0f - ax) + tx(x1, y1) * ax;
 	return top * (1.0f - ay) + bot * ay;

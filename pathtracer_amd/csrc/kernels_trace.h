@@ -47,6 +47,7 @@ struct DevScene {
 	uint32_t n_nodes, n_tris, n_mats, n_spheres, n_light_tris, n_light_spheres;
 	const uint8_t *env; uint32_t env_w, env_h;
 	const uint8_t *tex; uint32_t tex_layers;
+	uint32_t tex_wrap_s, tex_wrap_t, tex_mag_filter; // GL enums, 0 = GL_REPEAT / GL_LINEAR
 };
 
 // device control block shared by the kernels of one context

@@ -20,6 +20,8 @@
 #include "kernels_shade.h"
 #include "bvh_device.h"
 
+static_assert(sizeof(pt_config) == 64 && sizeof(pt_scene_desc) == 136 && sizeof(pt_counters) == 128, "C ABI structs changed size: update include/pt355.h, pathtracer_amd/__init__.py and tests/test_abi.py together");
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -464,6 +466,10 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 		return fail(c, PT_EINVAL, "pt_upload_scene: node/triangle indices are stored as floats and stop being exact above 2^24");
 	if ((s->n_spheres && !s->spheres) || (s->n_light_tris && !s->light_tris) || (s->n_light_spheres && !s->light_spheres))
 		return fail(c, PT_EINVAL, "pt_upload_scene: null array with non-zero count");
+	for (uint32_t m : {s->tex_wrap_s, s->tex_wrap_t})
+		if (m != 0u && m != 10497u && m != 33071u && m != 33648u) return fail(c, PT_EINVAL, "pt_upload_scene: texture wrap mode %u is not GL_REPEAT, GL_CLAMP_TO_EDGE or GL_MIRRORED_REPEAT", m);
+	if (s->tex_mag_filter != 0u && s->tex_mag_filter != 9728u && s->tex_mag_filter != 9729u)
+		return fail(c, PT_EINVAL, "pt_upload_scene: texture magnification filter %u is not GL_NEAREST or GL_LINEAR", s->tex_mag_filter);
 	if ((s->n_nodes & 1u) == 0) return fail(c, PT_EINVAL, "pt_upload_scene: a sibling-pair BVH has an odd node count (got %u)", s->n_nodes);
 	// host-side shape checks so that no kernel can index out of bounds
 	{
@@ -520,6 +526,7 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 	if (s->tex_rgb8 && s->tex_layers) {
 		if ((rc = upload(c, s->tex_rgb8, (size_t) s->tex_layers * 512 * 512 * 3, &b))) return rc;
 		d.tex = b; d.tex_layers = s->tex_layers;
+		d.tex_wrap_s = s->tex_wrap_s; d.tex_wrap_t = s->tex_wrap_t; d.tex_mag_filter = s->tex_mag_filter;
 	}
 	d.n_nodes = s->n_nodes; d.n_tris = s->n_tris; d.n_mats = s->n_materials; d.n_spheres = s->n_spheres;
 	d.n_light_tris = s->n_light_tris; d.n_light_spheres = s->n_light_spheres;

@@ -27,7 +27,8 @@ class oracle_scene(ctypes.Structure):
                 ("nodes", c_void_p), ("n_nodes", c_uint32),
                 ("light_spheres", c_void_p), ("n_light_spheres", c_uint32),
                 ("env_rgb8", c_void_p), ("env_w", c_uint32), ("env_h", c_uint32),
-                ("tex_rgb8", c_void_p), ("tex_layers", c_uint32)]
+                ("tex_rgb8", c_void_p), ("tex_layers", c_uint32),
+                ("tex_wrap_s", c_uint32), ("tex_wrap_t", c_uint32), ("tex_mag_filter", c_uint32)]
 
 
 class oracle_counters(ctypes.Structure):
@@ -65,7 +66,7 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(c_void_p)
 
 
-def scene_from_desc(d, env_rgb8=None, tex_rgb8=None):
+def scene_from_desc(d, env_rgb8=None, tex_rgb8=None, tex_sampler=None):
     """Build an oracle_scene from a pathtracer_amd pt_scene_desc (same field order by design)."""
     s = oracle_scene()
     for name, _ in oracle_scene._fields_:
@@ -79,6 +80,8 @@ def scene_from_desc(d, env_rgb8=None, tex_rgb8=None):
         tex = np.ascontiguousarray(tex_rgb8, np.uint8)
         s.tex_rgb8, s.tex_layers = tex.ctypes.data, tex.shape[0]
         keep.append(tex)
+    if tex_sampler is not None:
+        s.tex_wrap_s, s.tex_wrap_t, s.tex_mag_filter = tex_sampler
     s._keep = keep
     return s
 

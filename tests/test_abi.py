@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(pt):
 
 def test_struct_layouts_match_the_header(pt):
     assert ctypes.sizeof(pt.pt_config) == 64
-    assert ctypes.sizeof(pt.pt_scene_desc) == 6 * 16 + 16 + 16
+    assert ctypes.sizeof(pt.pt_scene_desc) == 6 * 16 + 16 + 24  # six arrays, env map, texture array + its sampler state
     assert ctypes.sizeof(pt.pt_counters) == 16 * 8
 
 

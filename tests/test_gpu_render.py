@@ -200,6 +200,31 @@ def test_textured_materials(pt, ol):
     assert not np.array_equal(ref, untextured)  # the layers are really being sampled
 
 
+@pytest.mark.parametrize("sampler", ["clamp_clamp_linear", "mirror_repeat_nearest", "repeat_mirror_linear"])
+def test_texture_sampler_state(pt, ol, sampler):
+    """Wrap modes / magnification filter of the texture array (the glTF sampler the loader applies, loader.cpp:242-251):
+    uvs run from -0.25 to 2.75, so every mode gives a different image, each bit-identical to the oracle's."""
+    modes = {"clamp_clamp_linear": (pt.GL_CLAMP_TO_EDGE, pt.GL_CLAMP_TO_EDGE, pt.GL_LINEAR),
+             "mirror_repeat_nearest": (pt.GL_MIRRORED_REPEAT, pt.GL_REPEAT, pt.GL_NEAREST),
+             "repeat_mirror_linear": (pt.GL_REPEAT, pt.GL_MIRRORED_REPEAT, pt.GL_LINEAR)}[sampler]
+    scene, tex = _textured_scene(pt)
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 3)
+    c = pt.PathTracer(96, 96, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+    try:
+        c.upload_scene(scene, tex_rgb8=tex, tex_sampler=modes)
+        c.set_camera(cam)
+        c.render(0, seeds, 5)
+        img = c.read_framebuffer()
+        with pytest.raises(pt.PtError):
+            c.upload_scene(scene, tex_rgb8=tex, tex_sampler=(1234, pt.GL_REPEAT, pt.GL_LINEAR))
+    finally:
+        c.close()
+    ref, _ = ol.render(ol.scene_from_desc(scene.desc(), tex_rgb8=tex, tex_sampler=modes), cam, 96, 96, seeds)
+    default, _ = ol.render(ol.scene_from_desc(scene.desc(), tex_rgb8=tex), cam, 96, 96, seeds)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert not np.array_equal(ref, default)
+
+
 @pytest.mark.parametrize("est", ["nee", "brdf"])
 @pytest.mark.parametrize("name", ["cornell_spheres", "bunny_ggx_env"])
 def test_alternative_estimators(pt, ol, est, name):
