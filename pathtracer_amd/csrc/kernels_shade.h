@@ -519,6 +519,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
+	// a block wholly past its region's fill has nothing to read and nothing to claim (the grid covers every slot of
+	// the queue because the fill counts live on the device): leave before the block-wide compaction
+	if (blockIdx.x * blockDim.x - in_region * a.cap >= n_in) return;
 	bool alive = i - in_region * a.cap < n_in;
 
 	uint32_t pixel = 0 /* path id in the batch */, rng = 0, meta = 0;
@@ -690,6 +693,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_alt(ShadeArgs a)
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
 	const bool nee_est = a.estimator == PT_EST_NEE;
+	// a block wholly past its region's fill has nothing to read and nothing to claim (the grid covers every slot of
+	// the queue because the fill counts live on the device): leave before the block-wide compaction
+	if (blockIdx.x * blockDim.x - in_region * a.cap >= n_in) return;
 	bool alive = i - in_region * a.cap < n_in;
 	bool emit_bounce = false, emit_shadow = false;
 
