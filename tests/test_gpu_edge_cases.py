@@ -1,0 +1,112 @@
+"""Edge cases of the path: a scene without any light (the only case in which the shader's GGX-without-NEE emission
+add, framebuffer.comp:1071-1077, and its num_lights == 0 guards are live), empty inputs, the smallest image, zero
+bounces, a single-triangle scene."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _env(seed=5, w=64, h=32):
+    rng = np.random.default_rng(seed)
+    env = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    env[: h // 3] = [250, 240, 200]  # a bright sky band so that the paths pick up energy
+    return env
+
+
+def _lightless_scene(pt):
+    s = pt.Scene()
+    grey = s.add_material([0.7, 0.7, 0.7], [0, 0, 0], [0, 0, 0])
+    rough = s.add_material([0.6, 0.5, 0.4], [0, 0, 0], [0, 0, 0], roughness=0.15, mat_type=pt.MAT_OREN_NAYAR)
+    gold = s.add_material([0, 0, 0], [0.944, 0.776, 0.373], [0, 0, 0], roughness=0.2, mat_type=pt.MAT_SPECULAR_METAL)
+    mirror = s.add_material([0, 0, 0], [0.9, 0.9, 0.9], [0, 0, 0], roughness=0.01, mat_type=pt.MAT_SPECULAR_METAL)
+
+    def quad(a, b, c, d, mat):
+        a, b, c, d = (np.array(p, np.float32) for p in (a, b, c, d))
+        n = np.cross(b - a, c - a)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        s.add_triangles(np.stack([np.concatenate([a, b, c]), np.concatenate([a, c, d])]), np.tile(n, (2, 3)), [mat, mat])
+
+    quad([-3, -1, -3], [3, -1, -3], [3, -1, -9], [-3, -1, -9], grey)              # floor
+    quad([-1.5, -1, -7], [0, -1, -7.5], [0, 1, -7.5], [-1.5, 1, -7], gold)        # two standing slabs
+    quad([0.3, -1, -6.5], [1.8, -1, -6.0], [1.8, 0.8, -6.0], [0.3, 0.8, -6.5], rough)
+    s.add_sphere([0.0, -0.4, -5.0], 0.6, mirror)
+    # emits red only: FindEmissiveSpheres wants ALL Le components > 1e-4 (src/scene/sphere.cpp:11-24), so this emitter is in
+    # no light list -- the scene stays "light-less" for NEE and its emission arrives through fc:889-896 / fc:1071-1077 alone
+    red_glow = s.add_material([0, 0, 0], [0, 0, 0], [6.0, 0.0, 0.0], mat_type=pt.MAT_LIGHT)
+    s.add_sphere([-1.6, 0.2, -5.5], 0.35, red_glow)
+    s.finalize()
+    assert s.arrays()["light_tris"].size == 0 and s.arrays()["light_spheres"].size == 0
+    return s
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 5])
+def test_scene_without_lights(pt, ol, bounces):
+    scene, env = _lightless_scene(pt), _env()
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 4)
+    c = pt.PathTracer(96, 64, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+    try:
+        c.upload_scene(scene, env_rgb8=env)
+        c.set_camera(cam)
+        c.render(0, seeds, bounces)
+        img = c.read_framebuffer()
+        cnt = c.counters()
+    finally:
+        c.close()
+    ref, ocnt = ol.render(ol.scene_from_desc(scene.desc(), env_rgb8=env), cam, 96, 64, seeds, bounces=bounces)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    assert cnt["rays_shadow"] == ocnt["rays_shadow"] == 0          # no light, no next-event estimation
+    assert cnt["rays_bounce"] == ocnt["rays_bounce"]
+    assert img[..., :3].max() > 0.0
+
+
+def test_estimators_without_lights(pt, ol):
+    scene, env = _lightless_scene(pt), _env()
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 3)
+    for est, oflag in ((pt.PT_ESTIMATOR_NEE, 2), (pt.PT_ESTIMATOR_BRDF, 4)):
+        c = pt.PathTracer(64, 64, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+        try:
+            c.upload_scene(scene, env_rgb8=env)
+            c.set_camera(cam)
+            c.set_estimator(est)
+            c.render(0, seeds, 4)
+            img = c.read_framebuffer()
+        finally:
+            c.close()
+        ref, _ = ol.render(ol.scene_from_desc(scene.desc(), env_rgb8=env), cam, 64, 64, seeds, bounces=4, flags=oflag)
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), est
+
+
+def test_empty_inputs_are_no_ops(pt):
+    c = pt.PathTracer(8, 8)
+    try:
+        c.upload_scene(pt.Scene.cornell())
+        c.set_camera(pt.default_camera())
+        prim, th, kind, uv = c.trace_closest(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+        assert prim.size == 0 and kind.size == 0
+        c.render(0, np.zeros(0, np.uint32), 5)                         # zero frames
+        c.sync()
+        assert not c.read_framebuffer().any()
+        assert c.counters()["paths"] == 0
+    finally:
+        c.close()
+
+
+def test_smallest_image_and_single_triangle(pt, ol):
+    s = pt.Scene()
+    m = s.add_material([0.5, 0.5, 0.5], [0, 0, 0], [3, 3, 3], mat_type=pt.MAT_LIGHT)
+    v = np.array([[-1, -1, -5, 1, -1, -5, 0, 1, -5]], np.float32)
+    n = np.array([[0, 0, 1, 0, 0, 1, 0, 0, 1]], np.float32)
+    s.add_triangles(v, n, [m])
+    s.finalize()                                                        # one triangle: the root is a leaf
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 2)
+    c = pt.PathTracer(8, 8)
+    try:
+        c.upload_scene(s)
+        c.set_camera(cam)
+        c.render(0, seeds, 5)
+        img = c.read_framebuffer()
+    finally:
+        c.close()
+    ref, _ = ol.render(ol.scene_from_desc(s.desc()), cam, 8, 8, seeds, bounces=5)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
