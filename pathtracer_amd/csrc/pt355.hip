@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,7 +54,6 @@ struct pt_ctx {
 
 	// scene
 	DevScene sc{};
-	void *nodes_alloc = nullptr;
 	std::vector<void *> scene_allocs;
 	bool have_scene = false, have_camera = false;
 	uint32_t estimator = PT_EST_MIS;
@@ -121,9 +121,8 @@ struct Range {
 	static pop_fn &pop() { static pop_fn f = nullptr; return f; }
 	static void resolve()
 	{
-		static bool done = false;
-		if (done) return;
-		done = true;
+		static std::once_flag once;
+		std::call_once(once, [] {
 		for (const char *name : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4"}) {
 			if (void *h = dlopen(name, RTLD_LAZY | RTLD_LOCAL)) {
 				push() = (push_fn) dlsym(h, "roctxRangePushA");
@@ -132,6 +131,7 @@ struct Range {
 				push() = nullptr; pop() = nullptr;
 			}
 		}
+		});
 	}
 	bool open = false;
 	explicit Range(const char *name) { resolve(); if (push()) { push()(name); open = true; } }
