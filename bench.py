@@ -31,6 +31,8 @@ def make_scene(pt, name):
         return pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
     if name == "bunny_ggx":  # configs[2]
         return pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_SPECULAR_METAL, roughness=0.2, spheres=True)
+    if name == "atrium":     # configs[3] stand-in: 281,620 triangles, 28 materials, texture layers 0..5
+        return pt.Scene.atrium(detail=4, seed=1)
     if name == "cornell":    # configs[0]
         return pt.Scene.cornell()
     raise SystemExit(f"unknown scene {name}")
@@ -96,7 +98,8 @@ def main():
     scene = make_scene(pt, args.scene)
     flags = pt.PT_FLAG_TRACE_DEAD_PATHS if args.trace_dead_paths else 0
     ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_FULL, max_batch=args.max_batch)
-    ctx.upload_scene(scene)
+    tex = pt.make_textures(6, 1) if args.scene == "atrium" else None
+    ctx.upload_scene(scene, tex_rgb8=tex)
     cam = pt.default_camera()
     ctx.set_camera(cam)
     # one seed table for the whole job, indexed by GLOBAL frame number: rank r renders frames r, r + world, ...
@@ -159,7 +162,7 @@ def main():
     if dist is not None and args.check and rank == 0:
         got = ctx.read_framebuffer()
         sctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, max_batch=args.max_batch)
-        sctx.upload_scene(scene)
+        sctx.upload_scene(scene, tex_rgb8=tex)
         sctx.set_camera(cam)
         timed = np.concatenate([seeds[r::world][args.warmup:] for r in range(world)])  # the frames of the timed region
         sctx.render(0, timed, args.bounces)
@@ -175,7 +178,7 @@ def main():
 
     # ---- roofline inputs for the dominant kernel (k_trace): S, T per ray from a counted replay of one batch
     cctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags | pt.PT_FLAG_COUNT_TRAVERSAL, max_batch=args.max_batch)
-    cctx.upload_scene(scene)
+    cctx.upload_scene(scene, tex_rgb8=tex)
     cctx.set_camera(cam)
     nc = min(cctx.max_batch, args.steps)
     cctx.render(args.warmup, mine[args.warmup: args.warmup + nc], args.bounces)
@@ -207,7 +210,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         import oracle_lib as ol
         threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
-        osc = ol.scene_from_desc(scene.desc())
+        osc = ol.scene_from_desc(scene.desc(), tex_rgb8=tex)
         nf = max(1, args.cpu_frames)
         c0 = time.perf_counter()
         _, oc = ol.render(osc, cam, args.width, args.height, pt.frame_seeds(args.warmup, nf), first_frame=args.warmup,
@@ -220,7 +223,7 @@ def main():
 
     d = scene.desc()
     out = {
-        "metric": "Mrays/s (closest-hit + NEE shadow rays), MIS path, bunny-class scene 1920x1080",
+        "metric": f"Mrays/s (closest-hit + NEE shadow rays), MIS path, {'bunny-class' if args.scene.startswith('bunny') else args.scene} scene {args.width}x{args.height}",
         "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

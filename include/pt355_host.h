@@ -82,6 +82,12 @@ int pth_scene_make_bunny(pth_scene *s, uint32_t subdiv, uint32_t target_tris, ui
                          float mesh_roughness, uint32_t flags);
 /* n_tris random small triangles in the box (BVH / traversal stress; LCG s = s*1664525+1013904223) */
 int pth_scene_make_soup(pth_scene *s, uint32_t n_tris, uint32_t seed, float size);
+/* "atrium", the Sponza-class stand-in of SURVEY.md 8(d) C4: tiled floor, two rows of eight tessellated columns joined by
+ * arches, textured walls, six ceiling light panels of different radiance, metal vases and spheres; 27 materials
+ * (Lambert / Oren-Nayar / GGX), six of them sampling texture layers 0..5; ~17,600 * detail^2 triangles (detail 4:
+ * 281 k).  pth_make_textures fills `layers` 512x512 RGB8 layers (six distinct procedural patterns) for it. */
+int pth_scene_make_atrium(pth_scene *s, uint32_t detail, uint32_t seed);
+int pth_make_textures(uint32_t layers, uint32_t seed, uint8_t *out);
 
 /* shaders/framebuffer.frag:8-26: NaN -> red, Inf -> green, else pow(rgb, 1/2.2); 8-bit RGB out, top row first */
 int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8);

@@ -105,6 +105,8 @@ EXPORTS = {
     "pth_scene_hash": (c_uint64, [c_void_p]),
     "pth_scene_make_cornell": (c_int, [c_void_p, c_uint32]),
     "pth_scene_make_bunny": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_int, c_float, c_uint32]),
+    "pth_scene_make_atrium": (c_int, [c_void_p, c_uint32, c_uint32]),
+    "pth_make_textures": (c_int, [c_uint32, c_uint32, c_void_p]),
     "pth_scene_make_soup": (c_int, [c_void_p, c_uint32, c_uint32, c_float]),
     "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
     "pth_write_ppm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
@@ -193,6 +195,13 @@ class Scene:
     def soup(cls, n_tris: int, seed: int = 7, size: float = 0.25) -> "Scene":
         s = cls()
         _check_host(lib().pth_scene_make_soup(s._h, n_tris, seed, size), "pth_scene_make_soup")
+        return s
+
+    @classmethod
+    def atrium(cls, detail: int = 4, seed: int = 1) -> "Scene":
+        """Sponza-class stand-in: ~17,600 * detail^2 triangles, 27 materials, texture layers 0..5."""
+        s = cls()
+        _check_host(lib().pth_scene_make_atrium(s._h, detail, seed), "pth_scene_make_atrium")
         return s
 
     def add_material(self, diffuse, specular, le, roughness=0.0, tex_index=-1, mat_type=MAT_LAMBERTIAN) -> int:
@@ -386,6 +395,13 @@ class PathTracer:
         out = np.empty_like(a)
         self._check(lib().pt_debug_eval(self._h, op, _ptr(a), _ptr(bb), a.size, _ptr(out)), "pt_debug_eval")
         return out
+
+
+def make_textures(layers: int = 6, seed: int = 1) -> np.ndarray:
+    """Procedural 512x512 RGB8 layers for Scene.atrium (u8 [layers, 512, 512, 3])."""
+    out = np.zeros((layers, 512, 512, 3), np.uint8)
+    _check_host(lib().pth_make_textures(layers, seed, _ptr(out)), "pth_make_textures")
+    return out
 
 
 def partition_pixels(width: int, height: int, partition: int, rank: int, world: int) -> np.ndarray:

@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../../include/pt355_host.h"
@@ -377,6 +378,194 @@ int pth_scene_make_soup(pth_scene *s, uint32_t n_tris, uint32_t seed, float size
 		push_tri(s, p[0], p[1], p[2], nrm, nrm, nrm, uvs, (i % 7 == 0) ? m.red : (uint32_t) grey);
 	}
 	return pth_scene_finalize(s);
+}
+
+// ---- "atrium": the C4-class stand-in of SURVEY.md 8(d) -- a hall with a tiled floor, two rows of tessellated columns
+// joined by arches, textured walls, several ceiling light panels of different radiance, a few metal objects: ~24
+// materials (Lambert / Oren-Nayar / GGX, six of them textured), ~16,000 * detail^2 triangles (detail 4 = 264 k).
+namespace {
+
+int add_tex_mat(pth_scene *s, float dr, float dg, float db, float rough, int tex, int type)
+{
+	const float d[3] = {dr, dg, db}, z[3] = {0, 0, 0};
+	return pth_scene_add_material(s, d, z, z, rough, tex, type);
+}
+
+// quad with explicit uvs (u along a->b, v along a->d), flat normal
+void push_quad_uv(pth_scene *s, Vec a, Vec b, Vec c, Vec d, float u0, float v0, float u1, float v1, uint32_t m)
+{
+	Vec nrm = vnorm(vcross(vsub(b, a), vsub(c, a)));
+	const float uv1[6] = {u0, v0, u1, v0, u1, v1}, uv2[6] = {u0, v0, u1, v1, u0, v1};
+	push_tri(s, a, b, c, nrm, nrm, nrm, uv1, m);
+	push_tri(s, a, c, d, nrm, nrm, nrm, uv2, m);
+}
+
+// surface of revolution about the vertical through (cx, cz): radius r(t), height y(t), t in [0,1]; smooth normals
+void push_revolved(pth_scene *s, float cx, float cz, float y0, float y1, const std::function<float(float)> &radius, uint32_t seg, uint32_t rings, uint32_t m)
+{
+	const float two_pi = 6.2831853f;
+	auto point = [&](uint32_t i, uint32_t j) {
+		const float t = (float) j / (float) rings, a = two_pi * (float) (i % seg) / (float) seg;
+		const float r = radius(t);
+		return Vec{cx + r * cosf(a), y0 + (y1 - y0) * t, cz + r * sinf(a)};
+	};
+	auto normal = [&](uint32_t i, uint32_t j) {
+		const float t = (float) j / (float) rings, a = two_pi * (float) (i % seg) / (float) seg;
+		const float dr = (radius(t + 1e-3f) - radius(t - 1e-3f)) / 2e-3f / (y1 - y0); // d radius / d height
+		return vnorm(Vec{cosf(a), -dr, sinf(a)});
+	};
+	for (uint32_t j = 0; j < rings; j++)
+		for (uint32_t i = 0; i < seg; i++) {
+			const Vec a = point(i, j), b = point(i + 1, j), c = point(i + 1, j + 1), d = point(i, j + 1);
+			const float u0 = (float) i / (float) seg, u1 = (float) (i + 1) / (float) seg, v0 = (float) j / (float) rings, v1 = (float) (j + 1) / (float) rings;
+			const float uv1[6] = {u0 * 4, v0 * 2, u1 * 4, v1 * 2, u1 * 4, v0 * 2}, uv2[6] = {u0 * 4, v0 * 2, u0 * 4, v1 * 2, u1 * 4, v1 * 2};
+			push_tri(s, a, c, b, normal(i, j), normal(i + 1, j + 1), normal(i + 1, j), uv1, m);
+			push_tri(s, a, d, c, normal(i, j), normal(i, j + 1), normal(i + 1, j + 1), uv2, m);
+		}
+}
+
+// half torus (an arch) springing at height y from (xa, za) to (xb, zb)
+void push_arch(pth_scene *s, float xa, float za, float xb, float zb, float y, float tube, uint32_t arc, uint32_t ring, uint32_t m)
+{
+	const float pi = 3.14159265f;
+	const float cx = 0.5f * (xa + xb), cz = 0.5f * (za + zb);
+	const float hx = 0.5f * (xb - xa), hz = 0.5f * (zb - za), R = sqrtf(hx * hx + hz * hz);
+	const Vec along{hx / R, 0.0f, hz / R}, side{-along.z, 0.0f, along.x};
+	auto frame = [&](uint32_t i, uint32_t j, Vec *p, Vec *n) {
+		const float a = pi * (float) i / (float) arc, b = 2.0f * pi * (float) (j % ring) / (float) ring;
+		const float ca = cosf(a), sa = sinf(a);
+		const Vec centre{cx - R * ca * along.x, y + R * sa, cz - R * ca * along.z};
+		const Vec out{-ca * along.x, sa, -ca * along.z};                 // from the arch's axis outwards
+		*n = vnorm(Vec{out.x * cosf(b) + side.x * sinf(b), out.y * cosf(b), out.z * cosf(b) + side.z * sinf(b)});
+		*p = Vec{centre.x + tube * n->x, centre.y + tube * n->y, centre.z + tube * n->z};
+	};
+	for (uint32_t i = 0; i < arc; i++)
+		for (uint32_t j = 0; j < ring; j++) {
+			Vec p[4], n[4];
+			frame(i, j, &p[0], &n[0]); frame(i + 1, j, &p[1], &n[1]); frame(i + 1, j + 1, &p[2], &n[2]); frame(i, j + 1, &p[3], &n[3]);
+			const float u0 = (float) i / (float) arc * 3, u1 = (float) (i + 1) / (float) arc * 3, v0 = (float) j / (float) ring, v1 = (float) (j + 1) / (float) ring;
+			const float uv1[6] = {u0, v0, u1, v0, u1, v1}, uv2[6] = {u0, v0, u1, v1, u0, v1};
+			push_tri(s, p[0], p[1], p[2], n[0], n[1], n[2], uv1, m);
+			push_tri(s, p[0], p[2], p[3], n[0], n[2], n[3], uv2, m);
+		}
+}
+
+} // namespace
+
+int pth_scene_make_atrium(pth_scene *s, uint32_t detail, uint32_t seed)
+{
+	if (detail == 0 || detail > 16) return PT_EINVAL;
+	Lcg rng{seed * 747796405u + 2891336453u};
+	const float x0 = -4.0f, x1 = 4.0f, y0 = -2.0f, y1 = 2.5f, z0 = -13.0f, z1 = -1.0f;
+	// materials: 0..5 textured (layers 0..5), then plain ones
+	const int tile_a = add_tex_mat(s, 0.85f, 0.85f, 0.85f, 0.0f, 0, PTH_MAT_LAMBERTIAN);
+	const int tile_b = add_tex_mat(s, 0.80f, 0.78f, 0.75f, 0.25f, 1, PTH_MAT_OREN_NAYAR);
+	const int wall_l = add_tex_mat(s, 0.9f, 0.9f, 0.9f, 0.2f, 2, PTH_MAT_OREN_NAYAR);
+	const int wall_r = add_tex_mat(s, 0.9f, 0.9f, 0.9f, 0.0f, 3, PTH_MAT_LAMBERTIAN);
+	const int wall_b = add_tex_mat(s, 1.0f, 1.0f, 1.0f, 0.3f, 4, PTH_MAT_OREN_NAYAR);
+	int brass_tex;
+	{
+		const float z[3] = {0, 0, 0}, f0[3] = {0.95f, 0.80f, 0.45f};
+		brass_tex = pth_scene_add_material(s, z, f0, z, 0.25f, 5, PTH_MAT_SPECULAR_METAL);
+	}
+	const int ceiling = add_mat(s, 0.75f, 0.75f, 0.78f, 0, 0, 0, 0, 0, 0, 0.0f, PTH_MAT_LAMBERTIAN);
+	int column_mat[8], arch_mat[4], light_mat[6];
+	for (int i = 0; i < 8; i++)
+		column_mat[i] = add_mat(s, 0.45f + 0.4f * rng.unit(), 0.45f + 0.4f * rng.unit(), 0.4f + 0.4f * rng.unit(), 0, 0, 0, 0, 0, 0,
+		                        0.05f + 0.3f * rng.unit(), PTH_MAT_OREN_NAYAR);
+	for (int i = 0; i < 4; i++)
+		arch_mat[i] = add_mat(s, 0.3f + 0.5f * rng.unit(), 0.3f + 0.5f * rng.unit(), 0.3f + 0.5f * rng.unit(), 0, 0, 0, 0, 0, 0, 0.0f, PTH_MAT_LAMBERTIAN);
+	const float le[6][3] = {{17, 12, 4}, {6, 8, 14}, {12, 12, 12}, {15, 6, 3}, {4, 10, 6}, {9, 9, 16}};
+	for (int i = 0; i < 6; i++) light_mat[i] = add_mat(s, 0, 0, 0, 0, 0, 0, le[i][0], le[i][1], le[i][2], 0.0f, PTH_MAT_LIGHT);
+	const int gold = add_mat(s, 0, 0, 0, 0.944f, 0.776f, 0.373f, 0, 0, 0, 0.15f, PTH_MAT_SPECULAR_METAL);
+	const int steel = add_mat(s, 0, 0, 0, 0.56f, 0.57f, 0.58f, 0, 0, 0, 0.3f, PTH_MAT_SPECULAR_METAL);
+	const int copper = add_mat(s, 0, 0, 0, 0.955f, 0.638f, 0.538f, 0, 0, 0, 0.08f, PTH_MAT_SPECULAR_METAL);
+
+	// floor tiles (checker of the two textured tile materials), ceiling, walls
+	const uint32_t tx = 8u * detail, tz = 12u * detail;
+	for (uint32_t i = 0; i < tx; i++)
+		for (uint32_t k = 0; k < tz; k++) {
+			const float ax = x0 + (x1 - x0) * (float) i / (float) tx, bx = x0 + (x1 - x0) * (float) (i + 1) / (float) tx;
+			const float az = z1 + (z0 - z1) * (float) k / (float) tz, bz = z1 + (z0 - z1) * (float) (k + 1) / (float) tz;
+			push_quad_uv(s, Vec{ax, y0, az}, Vec{bx, y0, az}, Vec{bx, y0, bz}, Vec{ax, y0, bz}, 0, 0, 1, 1, (uint32_t) (((i + k) & 1u) ? tile_a : tile_b));
+		}
+	push_quad(s, Vec{x0, y1, z0}, Vec{x1, y1, z0}, Vec{x1, y1, z1}, Vec{x0, y1, z1}, (uint32_t) ceiling);
+	push_quad_uv(s, Vec{x0, y0, z1}, Vec{x0, y0, z0}, Vec{x0, y1, z0}, Vec{x0, y1, z1}, -0.5f, -0.5f, 5.5f, 2.0f, (uint32_t) wall_l);
+	push_quad_uv(s, Vec{x1, y0, z0}, Vec{x1, y0, z1}, Vec{x1, y1, z1}, Vec{x1, y1, z0}, 0.0f, 0.0f, 6.0f, 2.25f, (uint32_t) wall_r);
+	push_quad_uv(s, Vec{x0, y0, z0}, Vec{x1, y0, z0}, Vec{x1, y1, z0}, Vec{x0, y1, z0}, -1.0f, 0.0f, 3.0f, 2.25f, (uint32_t) wall_b);
+	// six light panels just under the ceiling
+	for (int i = 0; i < 6; i++) {
+		const float cx = (i & 1) ? 1.6f : -1.6f, cz = -3.0f - 3.8f * (float) (i / 2), h = 0.45f, ly = y1 - 0.02f;
+		push_quad(s, Vec{cx - h, ly, cz - h}, Vec{cx + h, ly, cz - h}, Vec{cx + h, ly, cz + h}, Vec{cx - h, ly, cz + h}, (uint32_t) light_mat[i]);
+	}
+	// two rows of eight columns with entasis, base and capital; an arch from each column to the next of its row
+	const uint32_t seg = 16u * detail, rings = 24u * detail, arc = 16u * detail, ring = 8u * detail;
+	const float spring = 1.2f, pitch = 1.45f;
+	for (int row = 0; row < 2; row++) {
+		const float cx = row ? 2.4f : -2.4f;
+		for (int k = 0; k < 8; k++) {
+			const float cz = -2.2f - pitch * (float) k;
+			const float r0 = 0.22f + 0.04f * rng.unit();
+			auto shaft = [r0](float t) {
+				const float base = t < 0.06f ? 1.45f - 7.5f * t : 1.0f, cap = t > 0.92f ? 1.0f + 6.0f * (t - 0.92f) : 1.0f;
+				return r0 * base * cap * (1.0f - 0.12f * t * t) * (1.0f + 0.015f * sinf(60.0f * t));
+			};
+			push_revolved(s, cx, cz, y0, spring, shaft, seg, rings, (uint32_t) column_mat[(row * 3 + k) & 7]);
+			if (k < 7) push_arch(s, cx, cz, cx, cz - pitch, spring, 0.11f, arc, ring, (uint32_t) arch_mat[(row + k) & 3]);
+		}
+	}
+	// objects in the nave: three metal vases (one with the textured brass) and four analytic spheres
+	const int vase_mat[3] = {gold, brass_tex, steel};
+	for (int i = 0; i < 3; i++) {
+		const float cz = -4.0f - 3.2f * (float) i, cx = (i & 1) ? 0.7f : -0.7f;
+		auto profile = [](float t) { return 0.12f + 0.30f * sinf(3.0f * t + 0.3f) * sinf(3.0f * t + 0.3f) * (1.0f - 0.55f * t); };
+		push_revolved(s, cx, cz, y0, y0 + 1.1f, profile, seg, 16u * detail, (uint32_t) vase_mat[i]);
+	}
+	for (int i = 0; i < 4; i++) {
+		const float o[3] = {-1.2f + 0.8f * (float) i, y0 + 0.28f, -3.2f - 2.3f * (float) i};
+		pth_scene_add_sphere(s, o, 0.28f, (uint32_t) ((i & 1) ? copper : gold));
+	}
+	return pth_scene_finalize(s);
+}
+
+// Six seeded 512x512 RGB8 layers for the atrium's textured materials: checker, bricks, stripes, value-noise marble,
+// rings, speckle.  out: layers * 512 * 512 * 3 bytes (layers <= 6 are distinct, further ones repeat with another seed).
+int pth_make_textures(uint32_t layers, uint32_t seed, uint8_t *out)
+{
+	if (!out) return PT_EINVAL;
+	auto hash = [](uint32_t x, uint32_t y, uint32_t k) {
+		uint32_t h = x * 0x9e3779b1u ^ y * 0x85ebca77u ^ k * 0xc2b2ae3du;
+		h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+		return h;
+	};
+	auto noise = [&](float x, float y, uint32_t k) { // bilinear value noise in [0,1]
+		const int xi = (int) floorf(x), yi = (int) floorf(y);
+		const float fx = x - (float) xi, fy = y - (float) yi;
+		auto v = [&](int a, int b) { return (float) (hash((uint32_t) a & 63u, (uint32_t) b & 63u, k) >> 8) * (1.0f / 16777216.0f); };
+		const float top = v(xi, yi) * (1 - fx) + v(xi + 1, yi) * fx, bot = v(xi, yi + 1) * (1 - fx) + v(xi + 1, yi + 1) * fx;
+		return top * (1 - fy) + bot * fy;
+	};
+	for (uint32_t l = 0; l < layers; l++) {
+		const uint32_t k = seed * 31u + l / 6u * 977u + 1u;
+		for (uint32_t y = 0; y < 512; y++)
+			for (uint32_t x = 0; x < 512; x++) {
+				float r = 0, g = 0, b = 0;
+				const float u = (float) x / 512.0f, v = (float) y / 512.0f;
+				switch (l % 6u) {
+				case 0: { const bool c = ((x >> 6) + (y >> 6)) & 1u; r = c ? 0.92f : 0.25f; g = c ? 0.9f : 0.24f; b = c ? 0.85f : 0.3f; break; }
+				case 1: { const uint32_t row = y >> 5, xs = x + ((row & 1u) ? 32u : 0u); const bool mortar = (y & 31u) < 3u || (xs & 63u) < 3u;
+				          const float t = 0.75f + 0.25f * (float) (hash(xs >> 6, row, k) >> 24) / 255.0f; r = mortar ? 0.8f : 0.62f * t; g = mortar ? 0.8f : 0.27f * t; b = mortar ? 0.78f : 0.2f * t; break; }
+				case 2: { const float t = 0.5f + 0.5f * sinf(40.0f * u + 6.0f * noise(8 * u, 8 * v, k)); r = 0.3f + 0.6f * t; g = 0.35f + 0.4f * t; b = 0.5f; break; }
+				case 3: { const float t = noise(6 * u, 6 * v, k) * 0.6f + noise(24 * u, 24 * v, k + 7u) * 0.4f; const float m = 0.5f + 0.5f * sinf(18.0f * (u + v) + 9.0f * t);
+				          r = 0.85f - 0.35f * m; g = 0.85f - 0.4f * m; b = 0.9f - 0.3f * m; break; }
+				case 4: { const float d = sqrtf((u - 0.5f) * (u - 0.5f) + (v - 0.5f) * (v - 0.5f)); const float t = 0.5f + 0.5f * sinf(70.0f * d); r = 0.2f + 0.7f * t; g = 0.6f; b = 0.9f - 0.6f * t; break; }
+				default: { const float t = (float) (hash(x, y, k) >> 24) / 255.0f; r = 0.55f + 0.45f * t; g = 0.5f + 0.4f * t; b = 0.35f + 0.3f * t; break; }
+				}
+				uint8_t *o = out + (((size_t) l * 512 + y) * 512 + x) * 3;
+				o[0] = (uint8_t) (r * 255.0f + 0.5f); o[1] = (uint8_t) (g * 255.0f + 0.5f); o[2] = (uint8_t) (b * 255.0f + 0.5f);
+			}
+	}
+	return PT_OK;
 }
 
 int pth_tonemap_rgb8(const float *rgba, uint32_t width, uint32_t height, uint8_t *rgb8)

@@ -51,6 +51,29 @@ def test_config3_262k_triangles_1080p(pt, ol):
     _vs_oracle(pt, ol, scene, W, H, 1)
 
 
+def test_config3_atrium_with_textured_materials_1080p(pt, ol):
+    """configs[3] as SURVEY.md 8(d) describes its stand-in: the seeded atrium (281,620 triangles, 28 materials of all three
+    BRDF families, six of them sampling the texture array, twelve light triangles of six radiances, four GGX spheres)."""
+    scene, tex = pt.Scene.atrium(detail=4, seed=1), pt.make_textures(6, 1)
+    a = scene.arrays()
+    assert a["tris"].shape[0] > 262000 and a["materials"].shape[0] >= 24 and a["light_tris"].size == 12
+    seeds = pt.frame_seeds(0, 1)
+    c = pt.PathTracer(W, H, flags=pt.PT_FLAG_TRACE_DEAD_PATHS)
+    try:
+        c.upload_scene(scene, tex_rgb8=tex)
+        c.set_camera(pt.default_camera())
+        c.render(0, seeds, 5)
+        img, cnt = c.read_framebuffer(), c.counters()
+    finally:
+        c.close()
+    ref, ocnt = ol.render(ol.scene_from_desc(scene.desc(), tex_rgb8=tex), pt.default_camera(), W, H, seeds, threads=16)
+    bad = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+    assert bad == 0, f"{bad} of {W * H} pixels differ"
+    for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce"):
+        assert cnt[k] == ocnt[k], k
+    assert np.isfinite(img).all() and img[..., :3].mean() > 0.05
+
+
 def test_config4_million_triangles(pt, ol):
     """configs[4] stand-in: 2*10^6 triangles at 3840x2160 -- primitive indices far beyond the hit record's u16 object
     index (the wrapped index feeds the MIS light pdf) and a BVH of ~3 M float-encoded node indices."""
