@@ -110,3 +110,28 @@ def test_smallest_image_and_single_triangle(pt, ol):
         c.close()
     ref, _ = ol.render(ol.scene_from_desc(s.desc()), cam, 8, 8, seeds, bounces=5)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+def test_contexts_release_their_memory(pt):
+    """Twelve 1080p contexts in a row (23 GB of queues each at the default batch) and a scene re-upload loop:
+    device memory must come back after pt_destroy / a new pt_upload_scene."""
+    import torch
+    torch.cuda.init()
+    free0, total = torch.cuda.mem_get_info(0)
+    scene = pt.Scene.soup(20000, seed=2)
+    for _ in range(12):
+        c = pt.PathTracer(1920, 1080)
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        c.render(0, pt.frame_seeds(0, 1), 2)
+        c.sync()
+        c.close()
+    c = pt.PathTracer(64, 64)
+    try:
+        for _ in range(50):
+            c.upload_scene(scene)          # each upload frees the previous scene's buffers
+        c.build_bvh_device(scene.arrays()["tris"], 2)
+    finally:
+        c.close()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 512 * 1024 * 1024, f"{(free0 - free1) / 2**20:.0f} MiB not returned"
