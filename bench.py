@@ -95,11 +95,16 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
 
-    scene = make_scene(pt, args.scene)
+    t_scene = time.perf_counter()
+    scene = make_scene(pt, args.scene)  # generator + the reference's single-threaded Sweep-SAH build (CalculateBVH)
+    t_scene = time.perf_counter() - t_scene
     flags = pt.PT_FLAG_TRACE_DEAD_PATHS if args.trace_dead_paths else 0
     ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_FULL, max_batch=args.max_batch)
     tex = pt.make_textures(6, 1) if args.scene == "atrium" else None
+    t_upload = time.perf_counter()
     ctx.upload_scene(scene, tex_rgb8=tex)
+    ctx.sync()
+    t_upload = time.perf_counter() - t_upload
     cam = pt.default_camera()
     ctx.set_camera(cam)
     # one seed table for the whole job, indexed by GLOBAL frame number: rank r renders frames r, r + world, ...
@@ -235,6 +240,7 @@ def main():
         "spp_per_s": round(args.steps * world / dt, 3), "mpaths_per_s": round(paths_total / dt / 1e6, 2),
         "rays": {"primary": cnt["rays_primary"], "shadow": cnt["rays_shadow"], "bounce": cnt["rays_bounce"], "scope": "rank0" if world > 1 else "all"},
         "stack_spills": cnt["stack_spills"], "roofline": roofline, "cpu_baseline": cpu,
+        "setup": {"scene_generation_and_cpu_bvh_build_s": round(t_scene, 3), "upload_incl_traversal_blob_ms": round(t_upload * 1e3, 2)},
     }
     if check is not None:
         out["check"] = check
