@@ -135,3 +135,26 @@ def test_contexts_release_their_memory(pt):
         c.close()
     free1, _ = torch.cuda.mem_get_info(0)
     assert free0 - free1 < 512 * 1024 * 1024, f"{(free0 - free1) / 2**20:.0f} MiB not returned"
+
+
+def test_main_equivalent_driver(pt, tmp_path):
+    """tools/pt355_main.cpp -- the reference's main() with the GL seam replaced -- renders frame by frame through
+    pt_render_frame; its accumulator must equal the batched pt_render of the same frames bit for bit."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.__file__), "pt355_main")
+    ppm, pfm = str(tmp_path / "m.ppm"), str(tmp_path / "m.pfm")
+    out = subprocess.run([exe, "5", "256", "144", ppm, pfm], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Calculated BVH for scene" in out.stdout
+    got = pt.read_pfm(pfm, 256, 144)
+    c = pt.PathTracer(256, 144)
+    try:
+        c.upload_scene(pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175, spheres=True))
+        c.set_camera(pt.default_camera())
+        c.render(0, pt.frame_seeds(0, 5), 5)
+        ref = c.read_framebuffer()
+    finally:
+        c.close()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert os.path.getsize(ppm) > 256 * 144 * 3
