@@ -148,6 +148,16 @@ int pt_trace_closest(pt_ctx *ctx, const float *ro, const float *rd, uint32_t n,
  * rd.z[n]; hit4 = one 16-byte record per ray, 16-byte aligned: {prim u32, t_h | kind<<16, u f32, v f32}.  Asynchronous. */
 int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
 
+/* No counterpart in the reference.  pt_trace_closest_device for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernel, same arguments, same hit records; the
+ * kernel's scratch (work-unit counters and statistics block, traversal-stack spill tail: 24 MiB) is a file-scope
+ * device array that every GPU the library runs on holds until the process ends, and the call makes no hipMalloc /
+ * hipFree / event creation.  At most PT_NOALLOC_MAX_RAYS rays per call (PT_EINVAL beyond).  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (any contexts, any streams) race; back-to-back calls on the
+ * context's stream are fine.  Asynchronous like pt_trace_closest_device; not timed in pt_counters. */
+#define PT_NOALLOC_MAX_RAYS (1u << 26)
+int pt_trace_closest_device_noalloc(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
+
 /* What pt_create settled on (no reference counterpart): info[0] frames per launch set, [1] pipelines, [2] queue stride
  * (slots), [3] slots per queue region, [4] paths per frame on this rank, [5] k_trace grid (blocks), [6..7] zero. */
 int pt_get_info(const pt_ctx *ctx, uint32_t info[8]);

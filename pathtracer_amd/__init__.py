@@ -72,6 +72,7 @@ EXPORTS = {
     "pt_framebuffer_device": (c_int, [c_void_p, POINTER(c_void_p)]),
     "pt_trace_closest": (c_int, [c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pt_trace_closest_device": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
+    "pt_trace_closest_device_noalloc": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),
     "pt_get_info": (c_int, [c_void_p, c_void_p]),
     "pt_get_counters": (c_int, [c_void_p, POINTER(pt_counters)]),
     "pt_reset_counters": (c_int, [c_void_p]),
@@ -350,6 +351,10 @@ class PathTracer:
 
     def trace_closest_device(self, ray6_ptr: int, n: int, hit4_ptr: int):
         self._check(lib().pt_trace_closest_device(self._h, c_void_p(ray6_ptr), n, c_void_p(hit4_ptr)), "pt_trace_closest_device")
+
+    def trace_closest_device_noalloc(self, ray6_ptr: int, n: int, hit4_ptr: int):
+        self._check(lib().pt_trace_closest_device_noalloc(self._h, c_void_p(ray6_ptr), n, c_void_p(hit4_ptr)),
+                    "pt_trace_closest_device_noalloc")
 
     def counters(self) -> dict:
         c = pt_counters()

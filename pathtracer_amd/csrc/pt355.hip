@@ -44,6 +44,26 @@ struct Pipe {
 
 } // namespace
 
+// ---- scratch of the allocation-free trace entry (pt_trace_closest_device_noalloc).  What k_trace needs beyond its
+// inputs and outputs -- the control block (work-unit counters, statistics) and the traversal-stack spill tail of every
+// wave of a capped grid -- lives in ONE file-scope device array instead of hipMalloc'ed memory: 41,088 B of DevCtl
+// (padded to 256-byte granules) + PT_NOALLOC_MAX_BLOCKS x 4 waves x 48 levels x 64 lanes x 4 B = 24 MiB.  Every GPU the
+// library is loaded on holds its own copy at its own address until the process ends; the array's NAME is a host-side
+// stand-in only and is never handed to a kernel or a hip* call: the per-device address from hipGetSymbolAddress is.
+#define PT_NOALLOC_MAX_BLOCKS 512u
+struct NoAllocScratch {
+	DevCtl ctl;
+	unsigned char pad[(256u - sizeof(DevCtl) % 256u) % 256u];
+	uint32_t spill[(size_t) PT_NOALLOC_MAX_BLOCKS * PT_TRACE_WAVES * PT_SPILL_STACK * 64];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+#define PT_MAX_DEVICES 64
+namespace {
+std::mutex g_scratch_mutex;
+NoAllocScratch *g_scratch_ptr[PT_MAX_DEVICES]; // device address of `scratch` on each device, resolved once with that device current
+} // namespace
+
 struct pt_ctx {
 	pt_config cfg;
 	hipStream_t stream = nullptr; // = pipe[0].stream: uploads, image copies, pack/unpack, the stand-alone trace entry
@@ -68,6 +88,7 @@ struct pt_ctx {
 	int last_resolved = -1;  // pipeline whose k_resolve was enqueued last (the next one waits for it)
 	bool in_flight = false;  // renders enqueued since the last join
 	float *fb = nullptr;
+	NoAllocScratch *noalloc = nullptr; // this device's copy of `scratch` (resolved in pt_create)
 
 	// timing
 	std::vector<EventPair> free_events;
@@ -278,6 +299,16 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 		}                                                                                             \
 	} while (0)
 	CREATE_TRY(hipSetDevice(cfg->device));
+	if (cfg->device < PT_MAX_DEVICES) {
+		// once per device, with that device current: every GPU holds its own copy of `scratch` at its own address
+		std::lock_guard<std::mutex> lock(g_scratch_mutex);
+		if (!g_scratch_ptr[cfg->device]) {
+			void *p = nullptr;
+			CREATE_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+			g_scratch_ptr[cfg->device] = (NoAllocScratch *) p;
+		}
+		c->noalloc = g_scratch_ptr[cfg->device];
+	}
 	hipDeviceProp_t prop;
 	CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
 	c->n_cu = prop.multiProcessorCount;
@@ -732,6 +763,40 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	ta.ctl = pp.ctl;
 	ta.spill = pp.spill;
 	return launch_trace(c, pp, ta);
+}
+
+// Same kernel, same results as pt_trace_closest_device, for callers that cannot allocate (HIP graph capture, tight
+// serving loops): control block and spill tail come from this device's copy of the file-scope `scratch` array, no
+// timing events are taken (the event pool may have to grow), and nothing on this path calls hipMalloc/hipFree.
+// The array is shared by every call on the device and keeps the last call's contents: the control block is cleared
+// on the stream in front of the launch (work-unit counters must start at zero; the spill tail is written before it is
+// read), and calls that overlap on one GPU -- from this or any other context of the process -- race on it.
+int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n, void *hit4_dev)
+{
+	if (!c || !ray6_dev || !hit4_dev) return PT_EINVAL;
+	if (!c->have_scene) return fail(c, PT_ESTATE, "pt_trace_closest_device_noalloc: upload a scene first");
+	if (n > PT_NOALLOC_MAX_RAYS)
+		return fail(c, PT_EINVAL, "pt_trace_closest_device_noalloc: %u rays exceed the entry point's maximum of %u per call", n, (unsigned) PT_NOALLOC_MAX_RAYS);
+	if (!c->noalloc) return fail(c, PT_ESTATE, "pt_trace_closest_device_noalloc: no static scratch on device %d (ordinal above %d)", c->cfg.device, PT_MAX_DEVICES - 1);
+	if (n == 0) return PT_OK;
+	HIP_TRY(c, hipSetDevice(c->cfg.device));
+	if (c->in_flight) { int rc = join(c); if (rc) return rc; }
+	NoAllocScratch *const sp = c->noalloc; // the device address, never the array's name
+	HIP_TRY(c, hipMemsetAsync(&sp->ctl, 0, sizeof(DevCtl), c->stream));
+	TraceArgs ta;
+	memset(&ta, 0, sizeof ta);
+	ta.sc = c->sc;
+	ta.seg[0].ray = (const float *) ray6_dev; ta.seg[0].hit = (uint4 *) hit4_dev;
+	ta.stride = n; ta.n_fixed = n; ta.n_segs = 1;
+	ta.cap = (((n + 63u) / 64u + PT_SHARDS - 1) / PT_SHARDS) * 64u; // whole 64-ray units per region
+	ta.refill_threshold = c->refill_threshold;
+	ta.ctl = &sp->ctl;
+	ta.spill = sp->spill;
+	// the spill tail is sized for PT_NOALLOC_MAX_BLOCKS blocks: k_trace is persistent, any grid drains the work counters
+	const uint32_t grid = (uint32_t) c->trace_grid < PT_NOALLOC_MAX_BLOCKS ? (uint32_t) c->trace_grid : PT_NOALLOC_MAX_BLOCKS;
+	hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+	HIP_TRY(c, hipGetLastError());
+	return PT_OK;
 }
 
 int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv)
