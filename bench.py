@@ -1,21 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s (closest-hit + NEE shadow rays) of the MIS path on the bunny-class scene at
-1920x1080 (BASELINE.json configs[1]).  One step = one frame = one sample per pixel over the whole image, per GPU.
+1920x1080 (BASELINE.json configs[1]).  One step = one frame = one sample per pixel over the whole image.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--partition samples|tiles] [--scene NAME|file.glb]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  The path shards with no data-path collective: the
-scene is replicated and the FRAMES are dealt round-robin (global frame f -> rank f % N, "sample-interleaved",
-SURVEY.md 8e), every rank rendering K full-resolution frames with the host-PCG seeds of its own global frame
-numbers -- per-GPU work is fixed as N grows (weak scaling), N*K samples per pixel are produced in all.  The only
-exchange is the finished framebuffer: one RCCL sum-reduce of (n_r / N_total) * mean_r to rank 0, inside the timed
-region.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU.  Started from a plain shell (no WORLD_SIZE in the environment) the script starts its own
+N ranks -- a child `python -m torch.distributed.run ... bench.py <same arguments>`, spawned BEFORE anything in this
+process touches the GPU -- and exits with the child's code; started by torch.distributed.run it is one rank.
+The path shards with no data-path collective; the scene is replicated; the only exchange is the finished framebuffer,
+inside the timed region.  Two partitions:
+
+  samples (default; weak scaling, configs[4])   global frame f -> rank f % N over the FULL image; every rank renders K
+            frames with the host-PCG seeds of its own global frame numbers, N*K samples per pixel in all; exchange =
+            one RCCL sum-reduce of (n_r / N_total) * mean_r to rank 0.
+  tiles   (strong scaling, configs[3])           8x8 tiles dealt round-robin, every rank renders all K frames for its own
+            pixels; the image is bit-identical to the 1-GPU image; exchange = one gather of packed tiles to rank 0.
+
+Timing: W warm-up frames (plus one untimed batch of the timed launch size when W is smaller), then `--repeats`
+(default 3) timed regions of EXACTLY K steps each, bracketed by barrier + synchronize, MAX over ranks; the MEDIAN
+region is reported.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,11 +47,13 @@ def make_scene(pt, name):
         return pt.Scene.atrium(detail=4, seed=1)
     if name == "cornell":    # configs[0]
         return pt.Scene.cornell()
+    if name.endswith((".glb", ".gltf")) and hasattr(pt.Scene, "from_gltf"):
+        return pt.Scene.from_gltf(name)  # the reference's LoadGLTF + the scene set-up of src/main.cpp:19-63
     raise SystemExit(f"unknown scene {name}")
 
 
-def pmc_traffic(workload_key):
-    """HBM-side bytes per k_trace launch from the committed rocprofv3 --pmc passes of this same workload
+def pmc_profile(workload_key):
+    """Per-launch PMC figures of k_trace from the committed rocprofv3 --pmc passes of this same workload
     (profiles/*_pmc_traffic.json, written by tools/prof_summary.py): bench.py cannot run the profiler on itself."""
     import glob
     best = None
@@ -53,24 +67,61 @@ def pmc_traffic(workload_key):
     return best
 
 
+def gather_ceiling(device, footprint_bytes, hot_share, active_lanes, waves_per_simd):
+    """Live measurement on this GPU (pathtracer_amd/libptubench.so = tools/ubench_gather.hip): lane-steps/s of dependent
+    64-byte record gathers with the trace kernel's footprint, L1-hit share, lane occupancy and resident waves, and no
+    arithmetic in between.  Returns (lane_steps_per_s, ns_per_wavestep) or None when the library is not built."""
+    path = os.path.join(ROOT, "pathtracer_amd", "libptubench.so")
+    if not os.path.exists(path):
+        return None
+    L = ctypes.CDLL(path)
+    L.ptu_gather_ceiling.restype = ctypes.c_int
+    L.ptu_gather_ceiling.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    ns, rate = ctypes.c_double(), ctypes.c_double()
+    rc = L.ptu_gather_ceiling(device, int(footprint_bytes), float(hot_share), int(active_lanes), int(waves_per_simd), 2000,
+                              ctypes.byref(ns), ctypes.byref(rate))
+    return (rate.value, ns.value) if rc == 0 else None
+
+
+def spawn_ranks(n):
+    """Plain-shell start with --gpus N > 1: run the N ranks as a child torch.distributed.run job.  Nothing in this
+    process has touched the GPU yet (a process that has must never be replaced or forked into GPU work)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps frames each; the median is reported")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="bunny")
     ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--partition", choices=["samples", "tiles"], default="samples",
+                    help="N > 1: samples = frames dealt round-robin (weak scaling), tiles = 8x8 screen tiles (strong scaling, bit-identical)")
     ap.add_argument("--max-batch", type=int, default=0, help="frames traced per launch set (0 = library default)")
     ap.add_argument("--trace-dead-paths", action="store_true", help="trace zero-throughput paths like the reference does")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=48)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; what the driver runs) or gloo (rehearsal of the N > 1 "
-                    "code path with several ranks sharing one GPU: the reduce then goes through host memory)")
-    ap.add_argument("--check", action="store_true", help="N > 1: compare the reduced image with a sequential render of the same "
-                    "N*K global frames on rank 0 (tolerance 2e-6 relative)")
+                    "code path with several ranks sharing one GPU: the exchange then goes through host memory)")
+    ap.add_argument("--check", action="store_true", help="N > 1: compare the exchanged image with a sequential render of the same "
+                    "frames on rank 0 (tiles: bit-identical; samples: 2e-6 relative)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -81,6 +132,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit(f"bench.py (rank {rank} of {world}) needs a HIP device: the path has no CPU fallback")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -92,27 +145,39 @@ def main():
             dist.init_process_group(args.dist_backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device: the path has no CPU fallback")
+    tiles = world > 1 and args.partition == "tiles"
+    K, W = args.steps, args.warmup
 
     t_scene = time.perf_counter()
     scene = make_scene(pt, args.scene)  # generator + the reference's single-threaded Sweep-SAH build (CalculateBVH)
     t_scene = time.perf_counter() - t_scene
     flags = pt.PT_FLAG_TRACE_DEAD_PATHS if args.trace_dead_paths else 0
-    ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_FULL, max_batch=args.max_batch)
-    tex = pt.make_textures(6, 1) if args.scene == "atrium" else None
+    if tiles:
+        ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_TILES, rank=rank, world=world,
+                            max_batch=args.max_batch)
+    else:
+        ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_FULL, max_batch=args.max_batch)
+    tex = pt.make_textures(6, 1) if args.scene == "atrium" else getattr(scene, "textures", None)
+    tex_sampler = getattr(scene, "tex_sampler", None)
     t_upload = time.perf_counter()
-    ctx.upload_scene(scene, tex_rgb8=tex)
+    ctx.upload_scene(scene, tex_rgb8=tex, tex_sampler=tex_sampler)
     ctx.sync()
     t_upload = time.perf_counter() - t_upload
     cam = pt.default_camera()
     ctx.set_camera(cam)
-    # one seed table for the whole job, indexed by GLOBAL frame number: rank r renders frames r, r + world, ...
-    n_global = (args.warmup + args.steps) * world
-    seeds = pt.frame_seeds(0, n_global)
-    mine = seeds[rank::world]
+    # one seed table for the whole job, indexed by GLOBAL frame number
+    if tiles or world == 1:
+        seeds = pt.frame_seeds(0, W + K)
+        mine = seeds                       # every rank renders every frame (for its own pixels)
+    else:
+        seeds = pt.frame_seeds(0, (W + K) * world)
+        mine = seeds[rank::world]          # rank r renders global frames r, r + world, ...
     n_pix = args.width * args.height
-    red = torch.zeros((n_pix, 4), dtype=torch.float32, device="cuda") if dist is not None else None
+    red = None
+    if dist is not None:
+        rows = n_pix if not tiles else max(pt.lib().pt_partition_count(args.width, args.height, pt.PT_PARTITION_TILES, r, world) for r in range(world))
+        red = torch.zeros((rows, 4), dtype=torch.float32, device="cuda")
+    full_ctx = None  # tiles: rank 0 assembles the gathered image in a full-image context of its own
 
     def sync_all():
         ctx.sync()
@@ -122,9 +187,23 @@ def main():
             torch.cuda.synchronize()
 
     def exchange(n_local, n_total):
-        # finished framebuffer -> rank 0: pack (tile order), weight, RCCL sum-reduce, unpack on rank 0
+        # finished framebuffer -> rank 0
         ctx.pack_owned(red.data_ptr())
         ctx.sync()
+        if tiles:
+            # gather of packed tiles (rows past a rank's own count are padding), then unpack rank by rank
+            if args.dist_backend == "nccl":
+                bufs = mg.gather_tiles(dist, red, rank, world)
+            else:
+                hb = mg.gather_tiles(dist, red.cpu(), rank, world)
+                bufs = [b.cuda() for b in hb] if hb is not None else None
+            if rank == 0:
+                torch.cuda.synchronize()
+                for r in range(world):
+                    full_ctx.unpack_from(bufs[r].data_ptr(), r, world)
+                full_ctx.sync()
+            return
+        # samples: pack (tile order), weight, RCCL sum-reduce, unpack on rank 0
         if args.dist_backend == "nccl":
             mg.reduce_samples(dist, red, n_local, n_total)
         else:
@@ -136,27 +215,42 @@ def main():
             ctx.unpack_from(red.data_ptr(), 0, 1)
             ctx.sync()
 
-    ctx.render(0, mine[: args.warmup], args.bounces)
+    if tiles and rank == 0:
+        full_ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_FULL, max_batch=1)
+
+    # ---- warm-up: W frames, and at least one launch set of the timed size (a smaller warm-up launches smaller kernels)
+    timed = mine[W: W + K]
+    ctx.render(0, mine[:W], args.bounces)
+    nb = min(ctx.max_batch, K)
+    if W < nb:
+        ctx.render(W, timed[:nb], args.bounces)
     if dist is not None:
-        exchange(args.warmup, args.warmup * world)  # warms RCCL's lazy connection set-up too
+        exchange(max(W, 1), max(W, 1) * (1 if tiles else world))  # warms RCCL's lazy connection set-up too
+    sync_all()
+
+    regions = []
+    for rep in range(max(1, args.repeats)):
         ctx.clear_framebuffer()
-    sync_all()
-    ctx.reset_counters()
-    sync_all()
-    t0 = time.perf_counter()
-    # the local frame count sets the blend weight, so each rank's image is the mean of its own samples
-    ctx.render(0 if dist is not None else args.warmup, mine[args.warmup:], args.bounces)
-    if dist is not None:
-        exchange(args.steps, args.steps * world)
-    sync_all()
-    dt = time.perf_counter() - t0
-    cnt = ctx.counters()
+        ctx.reset_counters()
+        sync_all()
+        t0 = time.perf_counter()
+        # the local frame count sets the blend weight, so each rank's image is the mean of its own samples
+        ctx.render(0, timed, args.bounces)
+        if dist is not None:
+            exchange(K, K * (1 if tiles else world))
+        sync_all()
+        dt = time.perf_counter() - t0
+        cnt = ctx.counters()
+        if dist is not None:
+            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        regions.append((dt, cnt))
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    dt, cnt = regions[order[len(order) // 2]]
     rays = cnt["rays_primary"] + cnt["rays_shadow"] + cnt["rays_bounce"]
 
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         tot = torch.tensor([rays, cnt["paths"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         rays_total, paths_total = int(tot[0].item()), int(tot[1].item())
@@ -165,49 +259,82 @@ def main():
 
     check = None
     if dist is not None and args.check and rank == 0:
-        got = ctx.read_framebuffer()
+        got = (full_ctx if tiles else ctx).read_framebuffer()
         sctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, max_batch=args.max_batch)
-        sctx.upload_scene(scene, tex_rgb8=tex)
+        sctx.upload_scene(scene, tex_rgb8=tex, tex_sampler=tex_sampler)
         sctx.set_camera(cam)
-        timed = np.concatenate([seeds[r::world][args.warmup:] for r in range(world)])  # the frames of the timed region
-        sctx.render(0, timed, args.bounces)
+        if tiles:
+            frames = timed
+        else:
+            frames = np.concatenate([seeds[r::world][W: W + K] for r in range(world)])  # the frames of the timed region
+        sctx.render(0, frames, args.bounces)
         seq = sctx.read_framebuffer()
         sctx.close()
-        err = np.abs(got[..., :3] - seq[..., :3]) / np.maximum(np.abs(seq[..., :3]), 1e-3)
-        check = {"max_rel_err_vs_sequential": float(err.max()), "ok": bool(err.max() < 2e-6)}
+        if tiles:
+            bad = int((got.view(np.uint32) != seq.view(np.uint32)).any(axis=2).sum())
+            check = {"differing_pixels_vs_1gpu": bad, "ok": bad == 0}
+        else:
+            err = np.abs(got[..., :3] - seq[..., :3]) / np.maximum(np.abs(seq[..., :3]), 1e-3)
+            check = {"max_rel_err_vs_sequential": float(err.max()), "ok": bool(err.max() < 2e-6)}
 
     if rank != 0:
         ctx.close()
         dist.destroy_process_group()
         return
 
-    # ---- roofline inputs for the dominant kernel (k_trace): S, T per ray from a counted replay of one batch
-    cctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags | pt.PT_FLAG_COUNT_TRAVERSAL, max_batch=args.max_batch)
-    cctx.upload_scene(scene, tex_rgb8=tex)
+    # ---- roofline of the dominant kernel (k_trace): S, T per ray and lane occupancy from a counted replay of one batch
+    cctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags | pt.PT_FLAG_COUNT_TRAVERSAL, partition=ctx.partition,
+                         rank=ctx.rank, world=ctx.world, max_batch=args.max_batch)
+    cctx.upload_scene(scene, tex_rgb8=tex, tex_sampler=tex_sampler)
     cctx.set_camera(cam)
-    nc = min(cctx.max_batch, args.steps)
-    cctx.render(args.warmup, mine[args.warmup: args.warmup + nc], args.bounces)
+    cctx.render(0, timed[: min(cctx.max_batch, K)], args.bounces)
     cc = cctx.counters()
+    trace_grid = int(cctx.info[5])
     cctx.close()
     crays = cc["rays_primary"] + cc["rays_shadow"] + cc["rays_bounce"]
     S, T = cc["node_steps"] / crays, cc["tri_tests"] / crays
-    bytes_per_ray = 64.0 * S + 64.0 * T + 96.0  # 64 B per node pair, 64 B per triangle, 96 B of queue traffic
+    lane_occ = (cc["node_steps"] + cc["tri_tests"]) / max(64.0 * cc["wave_iters"], 1.0)  # share of lanes working per traversal iteration
     launches = max(cnt["trace_launches"], 1)
     avg_launch_ms = cnt["ms_trace"] / launches  # HIP events recorded around every k_trace launch on the context's stream
     rays_per_launch = rays / launches
-    achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    sec = avg_launch_ms * 1e-3
     workload_key = f"{args.scene}-{args.width}x{args.height}-b{args.bounces}"
-    pmc = pmc_traffic(workload_key)
+    pmc = pmc_profile(workload_key)
+    pk = (pmc or {}).get("kernels", {}).get("k_trace", {})
     traffic = None
-    if pmc is not None:
-        k = pmc["kernels"]["k_trace"]
+    if pk.get("hbm_bytes_per_launch"):
         # per ray as profiled, scaled to this run's rays per launch (batch sizes may differ between the two runs)
-        traffic = round(k["hbm_bytes_per_launch"] / max(k["rays_per_launch"], 1.0) * rays_per_launch)
-    roofline = {"bound": "hbm", "kernel": "k_trace", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": (pmc or {}).get("source"),
-                "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_per_launch),
-                "bytes_per_ray": round(bytes_per_ray, 1), "node_steps_per_ray": round(S, 3), "tri_tests_per_ray": round(T, 3),
+        traffic = round(pk["hbm_bytes_per_launch"] / max(pk.get("rays_per_launch", 0.0), 1.0) * rays_per_launch)
+    # (1) what binds the kernel: the vector-memory path's rate of dependent 64-byte record gathers.  One lane-step = one
+    # lane fetching one 64-B record of the traversal blob (a node pair or a triangle): rays * (S + T) of them per launch.
+    d = scene.desc()
+    props = torch.cuda.get_device_properties(local_rank)
+    waves_per_simd = max(1, min(8, round(trace_grid / max(props.multi_processor_count, 1))))
+    blob_bytes = 64 * ((d.n_nodes - 1) // 2 + d.n_tris)
+    l1_hit = 1.0 - pk["l1_miss_share"] if "l1_miss_share" in pk else 0.915  # profiles/r01g_rocprof_summary.txt when the newer passes lack it
+    lane_steps = (S + T) * rays_per_launch
+    achieved_ls = lane_steps / sec / 1e9 if sec > 0 else 0.0
+    ceil = gather_ceiling(local_rank, blob_bytes, l1_hit, max(1, round(lane_occ * 64)), waves_per_simd)
+    # (2) SURVEY.md 8(d)'s figure, kept for the record: algorithmic bytes against the HBM peak.  The 7 MB blob is
+    # cache-served, so this "fraction" exceeds 1 and is NOT the binding roof; hbm_counter_frac is the HBM-side truth.
+    bytes_per_ray = 64.0 * S + 64.0 * T + 96.0
+    alg = bytes_per_ray * rays_per_launch / sec / 1e9 if sec > 0 else 0.0
+    roofline = {"bound": "vmem-gather", "kernel": "k_trace",
+                "achieved": round(achieved_ls, 2), "peak": round(ceil[0] / 1e9, 2) if ceil else None, "unit": "G lane-steps/s",
+                "frac": round(achieved_ls / (ceil[0] / 1e9), 4) if ceil else None,
+                "peak_source": ("measured live by pathtracer_amd/libptubench.so (tools/ubench_gather.hip: ptu_gather_ceiling): dependent 64-B "
+                                f"record gathers, 4 x dwordx4 per lane-step, table {blob_bytes} B = the traversal blob, {l1_hit:.3f} of the steps in a "
+                                f"16 KB hot set (the kernel's L1 hit share, {'PMC ' + pmc['source'].split(':')[0] if pmc and 'l1_miss_share' in pk else 'profiles/r01g_rocprof_summary.txt'}), "
+                                f"{max(1, round(lane_occ * 64))} of 64 lanes active (measured by the counted replay), {waves_per_simd} waves/SIMD, no arithmetic"
+                                if ceil else "libptubench.so not built"),
+                "peak_ns_per_wavestep": round(ceil[1], 2) if ceil else None,
+                "lane_occupancy": round(lane_occ, 4), "lane_steps_per_ray": round(S + T, 3),
+                "traffic": traffic, "traffic_source": (pmc or {}).get("source"),
+                "hbm_counter_frac": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic and sec > 0 else None,
+                "algorithmic_hbm": {"bound": "hbm", "achieved": round(alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / HBM_PEAK_GBS, 5),
+                                    "note": "SURVEY.md 8(d): (64 S + 64 T + 96) B per ray over the kernel time; above 1 because the scene is cache-resident",
+                                    "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_per_launch), "bytes_per_ray": round(bytes_per_ray, 1)},
+                "node_steps_per_ray": round(S, 3), "tri_tests_per_ray": round(T, 3),
                 "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_launch_ms, 4),
                 "trace_ms_total": round(cnt["ms_trace"], 3), "shade_ms_total": round(cnt["ms_shade"], 3)}
 
@@ -218,7 +345,7 @@ def main():
         osc = ol.scene_from_desc(scene.desc(), tex_rgb8=tex)
         nf = max(1, args.cpu_frames)
         c0 = time.perf_counter()
-        _, oc = ol.render(osc, cam, args.width, args.height, pt.frame_seeds(args.warmup, nf), first_frame=args.warmup,
+        _, oc = ol.render(osc, cam, args.width, args.height, pt.frame_seeds(W, nf), first_frame=W,
                           bounces=args.bounces, threads=threads)
         cdt = time.perf_counter() - c0
         orays = oc["rays_primary"] + oc["rays_shadow"] + oc["rays_bounce"]
@@ -226,18 +353,20 @@ def main():
                "sample": f"{nf} frame(s) of the same {args.width}x{args.height} workload (the oracle traces zero-throughput paths too)",
                "spp_per_s": round(nf / cdt, 4), "seconds": round(cdt, 2)}
 
-    d = scene.desc()
+    spp_total = K * (1 if (tiles or world == 1) else world)
     out = {
-        "metric": f"Mrays/s (closest-hit + NEE shadow rays), MIS path, {'bunny-class' if args.scene.startswith('bunny') else args.scene} scene {args.width}x{args.height}",
-        "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": f"Mrays/s (closest-hit + NEE shadow rays), MIS path, {'bunny-class' if args.scene.startswith('bunny') else os.path.basename(args.scene)} scene {args.width}x{args.height}",
+        "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.scene}: {d.n_tris} triangles, Sweep-SAH BVH {d.n_nodes} nodes, {args.width}x{args.height}, "
-                               f"{args.steps} spp per GPU, {args.bounces} bounces, MIS (BSDF + NEE), shadow rays closest-hit "
+                               f"{K} spp per GPU, {args.bounces} bounces, MIS (BSDF + NEE), shadow rays closest-hit "
                                f"(reference semantics), {ctx.max_batch} frames per launch set",
-                   "scene_hash": f"{scene.hash():016x}", "partition": "samples-interleaved" if world > 1 else "single",
+                   "scene_hash": f"{scene.hash():016x}",
+                   "partition": ("tiles" if tiles else "samples-interleaved") if world > 1 else "single",
                    "dead_paths": "traced" if args.trace_dead_paths else "retired"},
-        "spp_per_s": round(args.steps * world / dt, 3), "mpaths_per_s": round(paths_total / dt / 1e6, 2),
+        "repeats": len(regions), "region_ms": [round(r[0] * 1e3, 3) for r in regions],
+        "spp_per_s": round(spp_total / dt, 3), "mpaths_per_s": round(paths_total / dt / 1e6, 2),
         "rays": {"primary": cnt["rays_primary"], "shadow": cnt["rays_shadow"], "bounce": cnt["rays_bounce"], "scope": "rank0" if world > 1 else "all"},
         "stack_spills": cnt["stack_spills"], "roofline": roofline, "cpu_baseline": cpu,
         "setup": {"scene_generation_and_cpu_bvh_build_s": round(t_scene, 3), "upload_incl_traversal_blob_ms": round(t_upload * 1e3, 2)},
@@ -245,7 +374,10 @@ def main():
     if check is not None:
         out["check"] = check
     print(json.dumps(out))
+    sys.stdout.flush()
     ctx.close()
+    if full_ctx is not None:
+        full_ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

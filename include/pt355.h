@@ -98,7 +98,9 @@ typedef struct pt_counters {
 	double   ms_trace;       /* HIP-event time of all trace launches since the last reset */
 	double   ms_shade;       /* ... of raygen + shade launches */
 	uint64_t trace_launches;
-	uint64_t reserved[5];
+	uint64_t wave_iters;     /* only with PT_FLAG_COUNT_TRAVERSAL: wave-iterations of the traversal loop; (node_steps + tri_tests) /
+	                            (64 * wave_iters) = the share of lanes doing work per iteration */
+	uint64_t reserved[4];
 } pt_counters;
 
 int pt_create(const pt_config *cfg, pt_ctx **out);

@@ -49,7 +49,7 @@ class pt_scene_desc(ctypes.Structure):
 class pt_counters(ctypes.Structure):
     _fields_ = [("frames", c_uint64), ("paths", c_uint64), ("rays_primary", c_uint64), ("rays_shadow", c_uint64),
                 ("rays_bounce", c_uint64), ("node_steps", c_uint64), ("tri_tests", c_uint64), ("stack_spills", c_uint64),
-                ("ms_trace", c_double), ("ms_shade", c_double), ("trace_launches", c_uint64), ("reserved", c_uint64 * 5)]
+                ("ms_trace", c_double), ("ms_shade", c_double), ("trace_launches", c_uint64), ("wave_iters", c_uint64), ("reserved", c_uint64 * 4)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -270,6 +270,7 @@ class PathTracer:
         info = np.zeros(8, np.uint32)
         self._check(L.pt_get_info(h, _ptr(info)), "pt_get_info")
         self.max_batch, self.pipelines, self.queue_stride = int(info[0]), int(info[1]), int(info[2])
+        self.info = info  # pt_get_info: [5] = k_trace grid (blocks)
         self._scene = None
 
     def _check(self, rc, what):

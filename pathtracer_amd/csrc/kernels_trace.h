@@ -52,7 +52,7 @@ struct DevScene {
 
 // device control block shared by the kernels of one context
 struct DevCtl {
-	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, pad[11];
+	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, wave_iters, pad[10];
 	uint32_t qcount[2][PT_SHARDS * PT_SHARD_STRIDE];             // live entries of region r of queue q at [q][r*32]
 	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE];                 // trace work-unit counters, zeroed before each trace launch
 	unsigned long long rays_bounce[PT_SHARDS * (PT_SHARD_STRIDE / 2)]; // per-region statistics, summed by the host
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	float best_u = 0.0f, best_v = 0.0f;
 	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
 	float t_kill = -__builtin_inff();  // shadow rays: an accepted hit with t <= t_kill ends the traversal
-	uint32_t n_steps = 0, n_tests = 0, n_spills = 0;
+	uint32_t n_steps = 0, n_tests = 0, n_spills = 0, n_iters = 0; // n_iters: iterations of the traversal loop (wave-uniform)
 	// wave-uniform work state
 	bool exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0; // the unit this wave is handing out to its lanes
@@ -342,6 +342,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
 			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form -- DESIGN.md
 			// "What was tried".)
+			if (COUNT) n_iters++;
 			if (active) {
 				const bool tmode = tri < tri_end;
 				const float4 *p = (const float4 *) (blob + (tmode ? tri : cur));
@@ -395,6 +396,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 		if (lane == 0) {
 			atomicAdd(&a.ctl->node_steps, (unsigned long long) n_steps);
 			atomicAdd(&a.ctl->tri_tests, (unsigned long long) n_tests);
+			atomicAdd(&a.ctl->wave_iters, (unsigned long long) n_iters);
 		}
 	}
 	{

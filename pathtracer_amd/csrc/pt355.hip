@@ -865,6 +865,7 @@ int pt_get_counters(pt_ctx *c, pt_counters *out)
 			out->rays_bounce += h.rays_bounce[r * (PT_SHARD_STRIDE / 2)];
 		}
 		out->node_steps += h.node_steps; out->tri_tests += h.tri_tests; out->stack_spills += h.stack_spills;
+		out->wave_iters += h.wave_iters;
 	}
 	out->ms_trace = c->ms_trace; out->ms_shade = c->ms_shade; out->trace_launches = c->trace_launches;
 	return PT_OK;

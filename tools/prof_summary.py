@@ -67,6 +67,18 @@ for k in acc:
     if "FETCH_SIZE" in acc[k] or "WRITE_SIZE" in acc[k]:
         kern[k] = {"fetch_size_kb": f_, "write_size_kb": w_, "hbm_bytes_per_launch": (2.0 * f_ + w_) * 1024.0,
                    "launches_profiled": cnt[k].get("FETCH_SIZE", 0)}
+for k in kern:
+    tot, req = acc[k].get("TCP_TOTAL_CACHE_ACCESSES_sum"), acc[k].get("TCP_TCC_READ_REQ_sum")
+    if tot:
+        kern[k]["l1_miss_share"] = (req or 0.0) / tot
+    hit, miss = acc[k].get("TCC_HIT_sum"), acc[k].get("TCC_MISS_sum")
+    if hit is not None and miss is not None and hit + miss > 0:
+        kern[k]["l2_hit_rate"] = hit / (hit + miss)
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = short(row["Name"])
+        if k in kern:
+            kern[k]["avg_launch_ms_kernel_trace"] = float(row["AverageNs"]) / 1e6
 if "k_trace" in kern and plain.get("trace_launches"):
     kern["k_trace"]["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
 if kern:

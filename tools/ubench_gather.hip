@@ -54,6 +54,73 @@ __global__ __launch_bounds__(256) void k_gather_coop(const uint4 *__restrict__ t
 	if (acc == 0x12345678u) out[0] = acc;
 }
 
+// ---- the same measurement as a library call (pathtracer_amd/libptubench.so), for bench.py's roofline block: the rate
+// at which this GPU's vector-memory path serves dependent 64-byte record gathers (4 x dwordx4 per lane-step, like one
+// k_trace iteration) shaped like the trace kernel's: a table of the traversal blob's footprint, `hot_share` of the
+// steps landing in a small hot set (16 KB: L1-resident, standing for the top of the tree), `active_lanes` of 64 lanes
+// working, `waves_per_simd` resident waves -- and NO arithmetic between the gathers.  Measurement infrastructure, not
+// product code: nothing in libpt355.so calls it.
+__global__ __launch_bounds__(256) void k_gather_hot(const uint4 *__restrict__ tab, uint32_t n_rec, uint32_t hot_mask, uint32_t hot_cut, int steps,
+                                                    int active_lanes, uint32_t *out)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t idx = (uint32_t) (((unsigned long long) ((blockIdx.x * 256u + threadIdx.x) * 2654435761u) * n_rec) >> 32);
+	uint32_t acc = 0;
+	if ((int) lane < active_lanes) {
+		for (int s = 0; s < steps; s++) {
+			const uint4 *p = tab + 4u * (size_t) idx;
+			const uint4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+			const uint32_t x = (q0.x ^ q1.y ^ q2.z ^ q3.w) + (uint32_t) s * 0x9e3779b9u;
+			acc += x;
+			const uint32_t y = x * 0x85ebca6bu;
+			idx = (y >> 16) < hot_cut ? (x & hot_mask) : (uint32_t) (((unsigned long long) x * n_rec) >> 32);
+		}
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+
+extern "C" int ptu_gather_ceiling(int device, unsigned long long footprint_bytes, double hot_share, int active_lanes, int waves_per_simd,
+                                  int steps, double *ns_per_wavestep, double *lane_steps_per_s)
+{
+	if (hipSetDevice(device) != hipSuccess) return 1;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 1;
+	uint32_t n = (uint32_t) (footprint_bytes / 64);
+	if (n < 1024u) n = 1024u;
+	if (active_lanes < 1) active_lanes = 1;
+	if (active_lanes > 64) active_lanes = 64;
+	if (waves_per_simd < 1) waves_per_simd = 1;
+	if (waves_per_simd > 8) waves_per_simd = 8;
+	std::vector<uint32_t> h((size_t) n * 16);
+	uint32_t ctr = 12345;
+	for (auto &v : h) { uint32_t z = ctr++; z ^= z >> 16; z *= 0x85ebca6bu; z ^= z >> 13; z *= 0xc2b2ae35u; z ^= z >> 16; v = z; }
+	uint4 *tab = nullptr; uint32_t *out = nullptr;
+	if (hipMalloc(&tab, (size_t) n * 64) != hipSuccess) return 2;
+	if (hipMalloc(&out, 4) != hipSuccess) { hipFree(tab); return 2; }
+	hipMemcpy(tab, h.data(), (size_t) n * 64, hipMemcpyHostToDevice);
+	const uint32_t hot_cut = (uint32_t) (hot_share * 65536.0 + 0.5);
+	const int blocks = prop.multiProcessorCount * waves_per_simd; // 256-thread blocks: 4 waves = one per SIMD
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0); hipEventCreate(&e1);
+	float best = 1e30f;
+	for (int rep = 0; rep < 4; rep++) { // first one warms the caches
+		hipEventRecord(e0);
+		k_gather_hot<<<blocks, 256>>>(tab, n, 255u, hot_cut, steps, active_lanes, out);
+		hipEventRecord(e1);
+		if (hipEventSynchronize(e1) != hipSuccess) { hipFree(tab); hipFree(out); return 3; }
+		float ms = 0;
+		hipEventElapsedTime(&ms, e0, e1);
+		if (rep > 0 && ms < best) best = ms;
+	}
+	hipEventDestroy(e0); hipEventDestroy(e1);
+	hipFree(tab); hipFree(out);
+	const double wavesteps_per_cu = (double) waves_per_simd * 4 * steps;
+	if (ns_per_wavestep) *ns_per_wavestep = best * 1e6 / wavesteps_per_cu;
+	if (lane_steps_per_s) *lane_steps_per_s = (double) blocks * 4 * active_lanes * steps / (best * 1e-3);
+	return 0;
+}
+
+#ifndef PTU_LIBRARY
 int main(int argc, char **argv)
 {
 	const int steps = 2000;
@@ -114,3 +181,4 @@ int main(int argc, char **argv)
 	}
 	return 0;
 }
+#endif
