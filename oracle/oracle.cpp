@@ -14,7 +14,8 @@
 //     fixes them to the small deterministic polynomial forms ptm_* below so
 //     that a GPU implementation can match bit for bit; ORACLE_FLAG_LIBM swaps
 //     in glibc's sinf/cosf/tanf/acosf/atan2f to show the choice is immaterial
-//     beyond rounding noise (tests/test_oracle_math.py, tests/test_render_parity.py);
+//     beyond rounding noise (tests/test_oracle.py: test_transcendental_contract_is_close_to_libm,
+//     test_libm_variant_is_statistically_the_same_image);
 //   * pow(x,2) and pow(x,5) are repeated multiplication.
 #include "oracle.h"
 
@@ -1107,6 +1108,90 @@ int oracle_math(int op, const float *a, const float *b, uint32_t n, float *out)
 		}
 		out[i] = r;
 	}
+	return 0;
+}
+
+int oracle_probe(int what, const float *in, uint32_t n, float *out, uint32_t flags)
+{
+	Fn fn{(flags & ORACLE_FLAG_LIBM) != 0};
+	auto put = [](float *o, v3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; };
+	for (uint32_t i = 0; i < n; i++) {
+		switch (what) {
+		case ORACLE_PROBE_MAP_TO_UNIT_SPHERE: { const float *a = in + 2 * (size_t) i; put(out + 3 * (size_t) i, map_to_unit_sphere(fn, a[0], a[1])); break; }
+		case ORACLE_PROBE_TNB_ROWS: {
+			const float *a = in + 3 * (size_t) i;
+			m3 m = tnb_rows(V(a[0], a[1], a[2]));
+			put(out + 9 * (size_t) i, m.r0); put(out + 9 * (size_t) i + 3, m.r1); put(out + 9 * (size_t) i + 6, m.r2);
+			break;
+		}
+		case ORACLE_PROBE_MAP_TO_TRIANGLE: {
+			const float *a = in + 11 * (size_t) i;
+			put(out + 3 * (size_t) i, map_to_triangle(a[0], a[1], V(a[2], a[3], a[4]), V(a[5], a[6], a[7]), V(a[8], a[9], a[10])));
+			break;
+		}
+		case ORACLE_PROBE_COSINE_HEMISPHERE: {
+			const float *a = in + 5 * (size_t) i;
+			put(out + 3 * (size_t) i, normalize(map_to_unit_sphere(fn, a[0], a[1]) + V(a[2], a[3], a[4])));
+			break;
+		}
+		case ORACLE_PROBE_NDF: { const float *a = in + 4 * (size_t) i; out[i] = trowbridge_reitz_NDF(V(a[0], a[1], a[2]), V(0.0f, 1.0f, 0.0f), a[3]); break; }
+		case ORACLE_PROBE_PICK_WI: {
+			const float *a = in + 6 * (size_t) i;
+			uint32_t st = fbits(a[0]);
+			Mat m; memset(&m, 0, sizeof m);
+			m.d2[3] = a[4]; m.d1[3] = a[5]; m.d3[3] = -1.0f;
+			v3 wm; float c, pdf;
+			v3 wi = pick_wi(fn, V(a[1], a[2], a[3]), m, false, &wm, &c, &pdf, st);
+			float *o = out + 8 * (size_t) i;
+			put(o, wi); put(o + 3, wm); o[6] = c; o[7] = pdf;
+			break;
+		}
+		case ORACLE_PROBE_CALC_BRDF: {
+			const float *a = in + 18 * (size_t) i;
+			static const Scene empty{};
+			Ctx cx{empty, fn, Counters()};
+			Mat m; memset(&m, 0, sizeof m);
+			m.d1[0] = a[9]; m.d1[1] = a[10]; m.d1[2] = a[11]; m.d1[3] = a[16];
+			m.d2[0] = a[12]; m.d2[1] = a[13]; m.d2[2] = a[14]; m.d2[3] = a[15]; m.d3[3] = -1.0f;
+			const uint16_t uvs[2] = {0, 0};
+			put(out + 3 * (size_t) i, calc_BRDF(cx, V(a[0], a[1], a[2]), V(a[3], a[4], a[5]), V(a[6], a[7], a[8]), m, uvs, a[17] != 0.0f));
+			break;
+		}
+		case ORACLE_PROBE_OCT_DECODE: {
+			uint16_t h[3];
+			oct_decode(fbits(in[i]), h);
+			put(out + 3 * (size_t) i, V(h2f(h[0]), h2f(h[1]), h2f(h[2])));
+			break;
+		}
+		case ORACLE_PROBE_INVERSE3: {
+			const float *a = in + 9 * (size_t) i;
+			m3 m; m.r0 = V(a[0], a[1], a[2]); m.r1 = V(a[3], a[4], a[5]); m.r2 = V(a[6], a[7], a[8]);
+			m3 r = inverse(m);
+			put(out + 9 * (size_t) i, r.r0); put(out + 9 * (size_t) i + 3, r.r1); put(out + 9 * (size_t) i + 6, r.r2);
+			break;
+		}
+		default: return -1;
+		}
+	}
+	return 0;
+}
+
+int oracle_estimate(const oracle_scene *s, const float ro[3], const float rd[3], uint32_t n_samples, uint32_t bounces,
+                    uint32_t flags, uint32_t seed, double out_mean[3])
+{
+	Scene sc = view(s);
+	Ctx cx{sc, Fn{(flags & ORACLE_FLAG_LIBM) != 0}, Counters()};
+	double acc[3] = {0, 0, 0};
+	const v3 o = V(ro[0], ro[1], ro[2]), d = V(rd[0], rd[1], rd[2]);
+	for (uint32_t i = 0; i < n_samples; i++) {
+		uint32_t rng_state = seed3(i & 0xffffu, i >> 16, seed);
+		v3 c;
+		if (flags & ORACLE_FLAG_EST_BRDF) c = estimator_path_tracing_BRDF(cx, o, d, rng_state, bounces);
+		else if (flags & ORACLE_FLAG_EST_NEE) c = estimator_path_tracing_nee(cx, o, d, rng_state, bounces);
+		else c = estimator_path_tracing_mis(cx, o, d, rng_state, bounces);
+		acc[0] += c.x; acc[1] += c.y; acc[2] += c.z;
+	}
+	for (int k = 0; k < 3; k++) out_mean[k] = n_samples ? acc[k] / n_samples : 0.0;
 	return 0;
 }
 

@@ -5,10 +5,15 @@
  *
  * Parity status: the reference ships no golden vectors for this path and its
  * GLSL cannot be executed in the build container, so the
- * integrator half of this oracle is "parity unpinned" by the reference's own
- * fixtures; it is pinned instead by (i) line-by-line citation of
- * framebuffer.comp, (ii) the reference's own host TUs for every buffer it
- * consumes (oracle/_ref), and (iii) closed-form / libm cross-checks in tests/.
+ * integrator half of this oracle has no end-to-end pin by the reference
+ * ("parity unpinned" for whole frames).  Piecewise it is pinned by sources that
+ * do not share its text (tests/test_oracle_pins.py):
+ * (i) the reference's own CPU twins of the sampling helpers (src/math/math.cpp,
+ * run through oracle/_ref, tests/golden/ref_math.npz), (ii) closest hits of the
+ * reference's vendored BVH library (same file), (iii) the reference's own host
+ * TUs for every buffer it consumes (ref_host.npz), (iv) closed forms,
+ * quadrature and histograms for the BRDFs, the sampling densities and the
+ * radiance of analytic scenes; the rest by line-by-line citation.
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
@@ -72,6 +77,29 @@ enum {
 	ORACLE_OP_OREN_NAYAR = 13, ORACLE_OP_GGX_NEE = 14, ORACLE_OP_GGX_IS = 15
 };
 int oracle_math(int op, const float *a, const float *b, uint32_t n, float *out);
+/* Vector-valued probes of single shader functions, for tests that pin the restatement against sources that do NOT
+ * share its text: the reference's CPU twins in src/math/math.cpp (oracle/_ref), closed forms, quadrature, histograms.
+ * in: n records of `in_stride` floats, out: n records of `out_stride` floats (strides per probe below).
+ * flags: ORACLE_FLAG_LIBM selects glibc's transcendental functions. */
+enum {
+	ORACLE_PROBE_MAP_TO_UNIT_SPHERE = 0, /* fc:154-170  in (u, v)                      out xyz                                  2 -> 3 */
+	ORACLE_PROBE_TNB_ROWS = 1,           /* fc:141-152,907  in n.xyz                    out rows t, n, bt                        3 -> 9 */
+	ORACLE_PROBE_MAP_TO_TRIANGLE = 2,    /* fc:707-723  in (u, v, v0, v1, v2)           out xyz                                 11 -> 3 */
+	ORACLE_PROBE_COSINE_HEMISPHERE = 3,  /* fc:172-175  in (u, v, n.xyz)                out normalize(map_to_unit_sphere + n)    5 -> 3 */
+	ORACLE_PROBE_NDF = 4,                /* fc:505-514  in (wm.xyz, alpha)              out D(wm), wg = (0,1,0)                  4 -> 1 */
+	ORACLE_PROBE_PICK_WI = 5,            /* fc:563-589  in (rng bits, wo.xyz, type, roughness)  out wi, wm, cos, pdf             6 -> 8 */
+	ORACLE_PROBE_CALC_BRDF = 6,          /* fc:591-643  in (wo, wm, wi, diffuse rgb, F0 rgb, type, roughness, using_NEE)  out rgb 18 -> 3 */
+	ORACLE_PROBE_OCT_DECODE = 7,         /* fc:203-210  in (packed 2x fp16 as float bits)  out the f16vec3 normal widened        1 -> 3 */
+	ORACLE_PROBE_INVERSE3 = 8            /* inverse(mat3), fc:908  in 9 (rows)          out 9 (rows)                             9 -> 9 */
+};
+int oracle_probe(int what, const float *in, uint32_t n, float *out, uint32_t flags);
+
+/* Mean of n_samples evaluations of the selected estimator (flags: ORACLE_FLAG_EST_*) for ONE fixed camera ray, sample i
+ * using the PCG stream seed3(i, 0, seed) -- a Monte-Carlo radiance estimate that closed forms can be checked against
+ * without a camera in between.  out_mean: rgb as doubles. */
+int oracle_estimate(const oracle_scene *sc, const float ro[3], const float rd[3], uint32_t n_samples, uint32_t bounces,
+                    uint32_t flags, uint32_t seed, double out_mean[3]);
+
 uint16_t oracle_f2h(float f);
 float oracle_h2f(uint16_t h);
 /* seed3 + n pcg() draws for pixel (x,y) and frame seed: framebuffer.comp:111-128 */

@@ -20,6 +20,14 @@
 #include "scene/sphere.hpp"   // SphereGLSL, FindEmissiveSpheres (src/scene/sphere.hpp:7-18)
 #include "math/math.hpp"      // pixl::octahedral_normal_encoding (src/math/math.hpp)
 
+// the reference's vendored BVH library: an INDEPENDENT closest-hit (own traversal loop, own box and triangle arithmetic)
+#include <bvh/bvh.hpp>
+#include <bvh/sweep_sah_builder.hpp>
+#include <bvh/single_ray_traverser.hpp>
+#include <bvh/primitive_intersectors.hpp>
+#include <bvh/triangle.hpp>
+#include <vector>
+
 extern "C" {
 
 // sizes of the six layouts the boundary freezes
@@ -124,6 +132,74 @@ uint32_t ref_find_emissive_spheres(const void *spheres, uint32_t nspheres, const
 	Array<uint32> e = FindEmissiveSpheres(s, m);
 	for (uint32_t i = 0; i < e.size; i++) out[i] = e[i];
 	return e.size;
+}
+
+// ---- CPU twins of the shader's sampling helpers (src/math/math.cpp:132-194 == framebuffer.comp:141-175, 707-723).
+// The live path never calls them, but they are the reference author's own statement of the same math, so they pin the
+// oracle's restatement of those shader lines independently of the shader text.
+
+// src/math/math.cpp:132-151 (libm sinf/cosf)
+void ref_map_to_unit_sphere(const float uv[2], float out[3])
+{
+	glm::vec3 p = pixl::map_to_unit_sphere(glm::vec2(uv[0], uv[1]));
+	out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+// src/math/math.cpp:153-157
+void ref_cosine_hemisphere(const float uv[2], const float n[3], float out[3])
+{
+	glm::vec3 p = pixl::map_to_unit_hemisphere_cosine_weighted_criver(glm::vec2(uv[0], uv[1]), glm::vec3(n[0], n[1], n[2]));
+	out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+// src/math/math.cpp:159-175 over a Triangle built by its own constructor (edge1 = v1 - v0, edge2 = v2 - v0, triangle.cpp:12-17)
+void ref_map_to_triangle(const float uv[2], const float v[9], float out[3])
+{
+	glm::vec3 z(0.0f);
+	Triangle t(glm::vec3(v[0], v[1], v[2]), glm::vec3(v[3], v[4], v[5]), glm::vec3(v[6], v[7], v[8]), z, z, z, 0);
+	glm::vec3 p = pixl::map_to_triangle(glm::vec2(uv[0], uv[1]), t);
+	out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+// src/math/math.cpp:178-194: out = rows of the TRANSPOSED mat3(t, n, bt), i.e. t, n, bt -- what framebuffer.comp:907 uses
+void ref_construct_tnb(const float n_in[3], float out[9])
+{
+	glm::vec3 n(n_in[0], n_in[1], n_in[2]);
+	glm::mat3 m = pixl::construct_TNB_matrix(n); // = transpose(mat3(t, n, bt)): column j of m holds (t[j], n[j], bt[j])
+	// row i of m = (m[0][i], m[1][i], m[2][i]) = basis vector i
+	for (int i = 0; i < 3; i++)
+		for (int j = 0; j < 3; j++) out[3 * i + j] = m[j][i];
+}
+
+// Closest hit by the reference's vendored library itself: Sweep-SAH BVH over the given triangles (same builder call as
+// CalculateBVH, src/scene/bvh.cpp:31-45), SingleRayTraverser (thirdparty/bvh/include/bvh/single_ray_traverser.hpp:65-126:
+// same near-first child ordering, own slab test) and ClosestPrimitiveIntersector over bvh::Triangle::intersect
+// (triangle.hpp:99-126: a different Moeller-Trumbore arrangement, inclusive t bounds, no |det| cut-off).  Not bit-comparable
+// with the shader's arithmetic; agrees with it wherever the closest hit is not a near-tie.  prim indexes tris_in.
+void ref_bvh_closest_hits(const void *tris_in, uint32_t n_tris, const float *ro, const float *rd, uint32_t n_rays, float tmin, float tmax,
+                          uint32_t *prim, float *t_out)
+{
+	const TriangleGLSL *tg = (const TriangleGLSL *) tris_in;
+	std::vector<bvh::Triangle<float>> prims;
+	prims.reserve(n_tris);
+	for (uint32_t i = 0; i < n_tris; i++) {
+		const TriangleGLSL &t = tg[i];
+		prims.emplace_back(bvh::Vector3<float>(t.v0().x, t.v0().y, t.v0().z), bvh::Vector3<float>(t.v1().x, t.v1().y, t.v1().z),
+		                   bvh::Vector3<float>(t.v2().x, t.v2().y, t.v2().z));
+	}
+	auto [bboxes, centers] = bvh::compute_bounding_boxes_and_centers(prims.data(), prims.size());
+	auto global_bbox = bvh::compute_bounding_boxes_union(bboxes.get(), prims.size());
+	bvh::Bvh<float> tree;
+	bvh::SweepSahBuilder<bvh::Bvh<float>> builder(tree);
+	builder.build(global_bbox, bboxes.get(), centers.get(), prims.size());
+	bvh::ClosestPrimitiveIntersector<bvh::Bvh<float>, bvh::Triangle<float>> isect(tree, prims.data());
+	bvh::SingleRayTraverser<bvh::Bvh<float>> trav(tree);
+	for (uint32_t r = 0; r < n_rays; r++) {
+		bvh::Ray<float> ray(bvh::Vector3<float>(ro[3 * r], ro[3 * r + 1], ro[3 * r + 2]), bvh::Vector3<float>(rd[3 * r], rd[3 * r + 1], rd[3 * r + 2]), tmin, tmax);
+		auto hit = trav.traverse(ray, isect);
+		prim[r] = hit ? (uint32_t) hit->primitive_index : 0xffffffffu;
+		t_out[r] = hit ? hit->distance() : 0.0f;
+	}
 }
 
 } // extern "C"

@@ -1,5 +1,5 @@
 // Host-side packing of scene records into the boundary layouts (include/pt355_host.h).
-// Output bytes are pinned against the reference's own TUs by tests/test_host_packing.py.
+// Output bytes are pinned against the reference's own TUs by tests/test_host_vs_reference.py.
 #include <cmath>
 #include <cstring>
 

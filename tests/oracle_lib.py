@@ -58,6 +58,8 @@ def load():
         L.oracle_render.argtypes = [POINTER(oracle_scene), c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p, c_uint32,
                                     c_void_p, c_uint32, c_uint32, POINTER(oracle_counters)]
         L.oracle_pcg_stream.argtypes = [c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]
+        L.oracle_probe.argtypes = [c_int, c_void_p, c_uint32, c_void_p, c_uint32]
+        L.oracle_estimate.argtypes = [POINTER(oracle_scene), c_void_p, c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_void_p]
         _lib = L
     return _lib
 
@@ -122,6 +124,30 @@ def render(osc, cam12, width, height, seeds, first_frame=0, bounces=5, flags=0, 
                               threads, byref(cnt))
     assert rc == 0
     return rgba, cnt.as_dict()
+
+
+# oracle_probe: name -> (code, floats in, floats out) per record (oracle/oracle.h)
+PROBE = dict(MAP_TO_UNIT_SPHERE=(0, 2, 3), TNB_ROWS=(1, 3, 9), MAP_TO_TRIANGLE=(2, 11, 3), COSINE_HEMISPHERE=(3, 5, 3), NDF=(4, 4, 1),
+             PICK_WI=(5, 6, 8), CALC_BRDF=(6, 18, 3), OCT_DECODE=(7, 1, 3), INVERSE3=(8, 9, 9))
+
+
+def probe(what, records, flags=0):
+    code, n_in, n_out = PROBE[what]
+    a = np.ascontiguousarray(records, np.float32).reshape(-1, n_in)
+    out = np.zeros((a.shape[0], n_out), np.float32)
+    rc = load().oracle_probe(code, _p(a), a.shape[0], _p(out), flags)
+    assert rc == 0
+    return out
+
+
+def estimate(osc, ro, rd, n_samples, bounces=5, flags=0, seed=1):
+    """Mean radiance (rgb, float64) of n_samples estimator evaluations for one fixed ray."""
+    ro = np.ascontiguousarray(ro, np.float32).reshape(3)
+    rd = np.ascontiguousarray(rd, np.float32).reshape(3)
+    out = np.zeros(3, np.float64)
+    rc = load().oracle_estimate(byref(osc), _p(ro), _p(rd), n_samples, bounces, flags, seed, _p(out))
+    assert rc == 0
+    return out
 
 
 def pcg_stream(x, y, seed, n):
