@@ -41,7 +41,10 @@ typedef struct pt_ctx pt_ctx;
                                          the one-sided quirk of the compare, so the image differs where that quirk leaks light */
 #define PT_FLAG_SHADOW_FULL_TRAVERSAL 8u /* always traverse to the closest hit (like-for-like work counters against the oracle) */
 #define PT_FLAG_TRACE_DEAD_PATHS   2u /* keep tracing paths whose throughput is exactly 0 (the reference does,
-                                         framebuffer.comp:899-1078); default retires them: same image, fewer rays */
+                                         framebuffer.comp:899-1078); default retires them: fewer rays, and the same image
+                                         unless a later bounce of such a path would have produced inf or NaN (0 * NaN = NaN
+                                         in the shader's color += throughput * X, e.g. a light sample at zero distance) --
+                                         set the flag to reproduce those NaN pixels too */
 #define PT_FLAG_COUNT_TRAVERSAL    4u /* accumulate node-pair visits / triangle tests (slower; for roofline inputs) */
 
 /* pt_config.partition: how the image is shared between the ranks of one node */

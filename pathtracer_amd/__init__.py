@@ -294,10 +294,14 @@ class PathTracer:
         keep = [scene]
         if env_rgb8 is not None:
             env = np.ascontiguousarray(env_rgb8, np.uint8)
+            if env.ndim != 3 or env.shape[2] != 3 or np.asarray(env_rgb8).dtype != np.uint8:
+                raise PtError(f"upload_scene: env_rgb8 must be uint8 [H, W, 3], got {np.asarray(env_rgb8).dtype} {env.shape}")
             d.env_rgb8, d.env_h, d.env_w = env.ctypes.data, env.shape[0], env.shape[1]
             keep.append(env)
         if tex_rgb8 is not None:
             tex = np.ascontiguousarray(tex_rgb8, np.uint8)
+            if tex.ndim != 4 or tex.shape[1:] != (512, 512, 3) or np.asarray(tex_rgb8).dtype != np.uint8:
+                raise PtError(f"upload_scene: tex_rgb8 must be uint8 [layers, 512, 512, 3], got {np.asarray(tex_rgb8).dtype} {tex.shape}")
             d.tex_rgb8, d.tex_layers = tex.ctypes.data, tex.shape[0]
             keep.append(tex)
         self._check(lib().pt_upload_scene(self._h, byref(d)), "pt_upload_scene")

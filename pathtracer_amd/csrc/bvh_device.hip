@@ -293,6 +293,8 @@ int ptb_build_lbvh(hipStream_t stream, const void *tris_host, uint32_t n, uint32
 	B_TRY(hipStreamSynchronize(stream));
 	const uint32_t n_kept = tail[0] + tail[1];
 	const uint32_t n_nodes = 1u + 2u * n_kept;
+	// child links are stored as floats (BVHNodeGLSL): odd indices above 2^24 are not representable and would round to the wrong sibling pair
+	if (n_nodes > (1u << 24)) { snprintf(err, errlen, "pt_build_bvh_device: %u nodes exceed the 2^24 a float child index can address; raise max_leaf", n_nodes); return 1; }
 	B_TRY(hipMemcpyAsync(nodes_out, d_nodes, (size_t) n_nodes * sizeof(NodeOut), hipMemcpyDeviceToHost, stream));
 	B_TRY(hipMemcpyAsync(sorted_out, d_sorted, (size_t) n * 64, hipMemcpyDeviceToHost, stream));
 	B_TRY(hipStreamSynchronize(stream));

@@ -206,11 +206,14 @@ int pth_scene_finalize_with(pth_scene *s, pth_bvh_builder build, void *user)
 	std::vector<PtTriangle> unsorted(n);
 	for (size_t i = 0; i < n; i++)
 		pth_pack_triangle(&s->v[9 * i], &s->uv[6 * i], &s->n[9 * i], s->mat[i], &unsorted[i]);
-	s->tris.resize(n);
-	s->nodes.resize(2 * n + 1);
-	uint32_t nn = build(unsorted.data(), (uint32_t) n, s->nodes.data(), s->tris.data(), user);
+	// build into temporaries: a failed build must leave an earlier finalization untouched
+	std::vector<PtTriangle> sorted(n);
+	std::vector<PtNode> nodes(2 * n + 1);
+	uint32_t nn = build(unsorted.data(), (uint32_t) n, nodes.data(), sorted.data(), user);
 	if (nn == 0) return PT_EINVAL;
-	s->nodes.resize(nn);
+	nodes.resize(nn);
+	s->tris.swap(sorted);
+	s->nodes.swap(nodes);
 	s->light_tris.resize(n);
 	s->light_tris.resize(pth_find_emissive_tris(s->tris.data(), (uint32_t) n, s->materials.data(),
 	                                            (uint32_t) s->materials.size(), s->light_tris.data()));

@@ -159,16 +159,34 @@ struct Range {
 	~Range() { if (open && pop()) pop()(); }
 };
 
-void begin_timed(pt_ctx *c, Pipe &pp, int kind)
+// Timing events around a launch.  A failure here only loses a timing sample, never a launch: the pair is dropped and
+// the error text kept for pt_last_error (timed = false tells end_timed there is nothing to close).
+bool begin_timed(pt_ctx *c, Pipe &pp, int kind)
 {
 	EventPair ev;
+	ev.a = ev.b = nullptr;
 	if (!c->free_events.empty()) { ev = c->free_events.back(); c->free_events.pop_back(); }
-	else { hipEventCreate(&ev.a); hipEventCreate(&ev.b); }
+	else {
+		hipError_t e = hipEventCreate(&ev.a);
+		if (e == hipSuccess && (e = hipEventCreate(&ev.b)) != hipSuccess) { hipEventDestroy(ev.a); }
+		if (e != hipSuccess) { fail(c, PT_EHIP, "hipEventCreate: %s (launch not timed)", hipGetErrorString(e)); return false; }
+	}
 	ev.kind = kind;
-	hipEventRecord(ev.a, pp.stream);
+	hipError_t e = hipEventRecord(ev.a, pp.stream);
+	if (e != hipSuccess) { c->free_events.push_back(ev); fail(c, PT_EHIP, "hipEventRecord: %s (launch not timed)", hipGetErrorString(e)); return false; }
 	pp.pending.push_back(ev);
+	return true;
 }
-void end_timed(Pipe &pp) { hipEventRecord(pp.pending.back().b, pp.stream); }
+void end_timed(pt_ctx *c, Pipe &pp, bool timed)
+{
+	if (!timed) return;
+	hipError_t e = hipEventRecord(pp.pending.back().b, pp.stream);
+	if (e != hipSuccess) {
+		c->free_events.push_back(pp.pending.back());
+		pp.pending.pop_back();
+		fail(c, PT_EHIP, "hipEventRecord: %s (launch not timed)", hipGetErrorString(e));
+	}
+}
 
 // every pipeline idle: the image and the counters are complete
 int join(pt_ctx *c)
@@ -230,12 +248,12 @@ const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
 
 int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta)
 {
-	begin_timed(c, pp, 0);
+	const bool timed = begin_timed(c, pp, 0);
 	if (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL)
 		hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
 	else
 		hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
-	end_timed(pp);
+	end_timed(c, pp, timed);
 	c->trace_launches++;
 	HIP_TRY(c, hipGetLastError());
 	return PT_OK;
@@ -325,7 +343,8 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false>, PT_TRACE_BLOCK, 0));
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
-	// tuning knobs (defaults are the measured optimum)
+	// tuning knobs for experiments (tools/exp_*.py), read once per pt_create; defaults are the measured optimum (DESIGN.md
+	// section 7): PT355_PIPES (1..4), PT355_TRACE_BLOCKS_PER_CU, PT355_REFILL (1..64), PT355_BATCH (1..32).  None changes results.
 	if (const char *e = getenv("PT355_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= blocks_per_cu) blocks_per_cu = v; }
 	if (const char *e = getenv("PT355_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t) v; }
 	c->trace_grid = c->n_cu * blocks_per_cu;
@@ -614,18 +633,18 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	const dim3 sgrid(c->stride / PT_SHADE_BLOCK);
 
 	sa.out = pp.q[0];
-	begin_timed(c, pp, 1);
+	const bool timed_ = begin_timed(c, pp, 1);
 	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
-	end_timed(pp);
+	end_timed(c, pp, timed_);
 	uint32_t qi = 0;
 	if (c->estimator == PT_EST_MIS) {
 		for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
 			int rc = launch_trace(c, pp, queue_trace_args(c, pp, qi, stage > 0));
 			if (rc) return rc;
 			sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
-			begin_timed(c, pp, 1);
+			const bool timed_ = begin_timed(c, pp, 1);
 			hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, pp.stream, sa);
-			end_timed(pp);
+			end_timed(c, pp, timed_);
 			qi ^= 1u;
 		}
 	} else {
@@ -640,18 +659,18 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 			int rc = launch_trace(c, pp, ta);
 			if (rc) return rc;
 			sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
-			begin_timed(c, pp, 1);
+			const bool timed_ = begin_timed(c, pp, 1);
 			hipLaunchKernelGGL(k_shade_alt, sgrid, sblock, 0, pp.stream, sa);
-			end_timed(pp);
+			end_timed(c, pp, timed_);
 			qi ^= 1u;
 		}
 	}
 	// the running mean is order-dependent: this batch is blended after the previous one, whichever pipeline ran it
 	if (c->last_resolved >= 0 && (uint32_t) c->last_resolved != pi)
 		HIP_TRY(c, hipStreamWaitEvent(pp.stream, c->pipe[c->last_resolved].resolved, 0));
-	begin_timed(c, pp, 1);
+	const bool timed_r = begin_timed(c, pp, 1);
 	hipLaunchKernelGGL(k_resolve, dim3((c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
-	end_timed(pp);
+	end_timed(c, pp, timed_r);
 	HIP_TRY(c, hipEventRecord(pp.resolved, pp.stream));
 	c->last_resolved = (int) pi;
 	HIP_TRY(c, hipGetLastError());
@@ -937,8 +956,8 @@ int pt_debug_read_queue(pt_ctx *c, uint32_t queue, uint32_t field, void *out, si
 	const size_t need = (size_t) cols[field] * c->stride;
 	if (n_words != need) return fail(c, PT_EINVAL, "pt_debug_read_queue: field %u needs %zu words", field, need);
 	HIP_TRY(c, hipMemcpyAsync(out, base[field], need * 4, hipMemcpyDeviceToHost, c->stream));
-	static uint32_t qc[PT_SHARDS * PT_SHARD_STRIDE];
-	HIP_TRY(c, hipMemcpyAsync(qc, c->pipe[0].ctl->qcount[queue], sizeof qc, hipMemcpyDeviceToHost, c->stream));
+	std::vector<uint32_t> qc(PT_SHARDS * PT_SHARD_STRIDE);
+	HIP_TRY(c, hipMemcpyAsync(qc.data(), c->pipe[0].ctl->qcount[queue], qc.size() * 4, hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if (stride) *stride = c->stride;
 	if (count) { *count = 0; for (uint32_t r = 0; r < PT_SHARDS; r++) *count += qc[r * PT_SHARD_STRIDE]; }
@@ -980,15 +999,20 @@ int pt_debug_eval(pt_ctx *c, int op, const float *a, const float *b, uint32_t n,
 	if (n == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	float *da = nullptr, *db = nullptr, *dout = nullptr;
-	HIP_TRY(c, hipMalloc((void **) &da, (size_t) n * 4));
-	HIP_TRY(c, hipMalloc((void **) &dout, (size_t) n * 4));
-	if (b) HIP_TRY(c, hipMalloc((void **) &db, (size_t) n * 4));
-	hipMemcpyAsync(da, a, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
-	if (b) hipMemcpyAsync(db, b, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
-	hipLaunchKernelGGL(k_debug_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, (const float *) da, (const float *) db, n, dout);
-	hipMemcpyAsync(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream);
-	hipError_t e = hipStreamSynchronize(c->stream);
-	hipFree(da); hipFree(dout); if (db) hipFree(db);
+	hipError_t e = hipMalloc((void **) &da, (size_t) n * 4);
+	if (e == hipSuccess) e = hipMalloc((void **) &dout, (size_t) n * 4);
+	if (e == hipSuccess && b) e = hipMalloc((void **) &db, (size_t) n * 4);
+	if (e == hipSuccess) e = hipMemcpyAsync(da, a, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess && b) e = hipMemcpyAsync(db, b, (size_t) n * 4, hipMemcpyHostToDevice, c->stream);
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_debug_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, op, (const float *) da, (const float *) db, n, dout);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t) n * 4, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (da) hipFree(da);
+	if (dout) hipFree(dout);
+	if (db) hipFree(db);
 	if (e != hipSuccess) return fail(c, PT_EHIP, "pt_debug_eval: %s", hipGetErrorString(e));
 	return PT_OK;
 }
