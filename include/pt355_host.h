@@ -72,6 +72,42 @@ int pth_scene_finalize_with(pth_scene *s, pth_bvh_builder build, void *user);
 int pth_scene_desc(const pth_scene *s, pt_scene_desc *out);
 uint64_t pth_scene_hash(const pth_scene *s); /* FNV-1a over the six arrays, binding order */
 
+/* `count` MaterialGLSL records (48 bytes each) appended as they are; returns the index of the first one */
+uint32_t pth_scene_add_packed_materials(pth_scene *s, const void *materials48, uint32_t count);
+
+/* ---- glTF loader + Model: src/loader.h:4 LoadGLTF(path, Model&), src/scene/model.h:7-29 ------------------------
+ * Own parser (JSON, GLB, accessors; PNG textures over zlib) in place of the reference's vendored cgltf / stb; what the
+ * loader does with the data is the reference's, quirks included (per-mesh arrays appended per primitive, index byteOffset
+ * ignored, one material per primitive, metals -> Lambert roughness 2.0, y <-> z swap of node scale / translation, every
+ * node baked into all triangles): output bytes pinned against the reference's own loader, tests/test_gltf_loader.py.
+ * The GL texture array of src/loader.cpp:48-58, 242-265 becomes a host RGB8 layer array + the sampler's GL enums.
+ * Errors: return code != 0 and pth_last_error() (thread-local text); where the reference would crash (no indices, no
+ * normals, index out of range) this returns an error instead. */
+typedef struct pth_model pth_model;
+pth_model *pth_model_create(void);
+void pth_model_destroy(pth_model *m);
+const char *pth_last_error(void);
+int pth_load_gltf(const char *path, pth_model *out);                /* LoadGLTF, src/loader.cpp:13-401 */
+void pth_model_translate(pth_model *m, const float t[3]);           /* Model::Translate, src/scene/model.cpp:48-51 */
+void pth_model_rotate(pth_model *m, const float r[3]);              /* Model::Rotate (x, then y, then z; radians), :53-58 */
+void pth_model_scale(pth_model *m, const float s[3]);               /* Model::Scale, :60-68 */
+void pth_model_apply_matrix(pth_model *m);                          /* Model::ApplyModelMatrixToTris, :27-42 */
+uint32_t pth_model_triangle_count(const pth_model *m);
+uint32_t pth_model_material_count(const pth_model *m);
+/* copies out the fat triangles (v 9, n 9, uv 6 floats and the material index per triangle) and the MaterialGLSL records;
+ * any pointer may be NULL */
+int pth_model_get(const pth_model *m, float *v9, float *n9, float *uv6, uint32_t *mat, void *materials48);
+/* the texture array's content: layers x 512 x 512 x RGB8 (NULL when the file has no textures) and sampler[3] =
+ * {wrap_s, wrap_t, mag_filter} as GL enums -> pt_scene_desc.tex_rgb8 / tex_layers / tex_wrap_s / tex_wrap_t / tex_mag_filter */
+int pth_model_textures(const pth_model *m, const uint8_t **rgb8, uint32_t *layers, uint32_t sampler[3]);
+/* src/main.cpp:31-36: the model's triangles and materials become the scene's (then pth_scene_add_material / _sphere for
+ * src/main.cpp:44-51, then pth_scene_finalize) */
+int pth_scene_add_model(pth_scene *s, const pth_model *m);
+/* the two image steps of the textured path on their own (stbi_load_from_memory with 3 channels; stbir_resize_uint8 to
+ * 512 x 512: src/loader.cpp:209-232), exposed so tests can check each against the reference's stb build */
+int pth_decode_png_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels);
+int pth_resize_rgb8_512(const uint8_t *rgb, int w, int h, uint8_t *out512);
+
 /* Procedural stand-ins (no assets exist offline: the reference git-ignores .glb / .hdr files).
  * Cornell box: 5 walls + ceiling light quad + two boxes = 36 triangles, placed like src/main.cpp:26-28.
  * flags bit0: add the four gold GGX spheres of src/main.cpp:44-51. */

@@ -19,6 +19,10 @@
 #include "scene/material.hpp" // MaterialGLSL                 (src/scene/material.hpp:13-31)
 #include "scene/sphere.hpp"   // SphereGLSL, FindEmissiveSpheres (src/scene/sphere.hpp:7-18)
 #include "math/math.hpp"      // pixl::octahedral_normal_encoding (src/math/math.hpp)
+#include "loader.h"           // LoadGLTF (src/loader.h:4)
+#include "scene/model.h"      // Model (src/scene/model.h:7-29)
+#include <stb_image.h>        // the reference's vendored decoder (thirdparty/stb), as loader.cpp:209 calls it
+#include <stb_image_resize.h> // ... and resizer, as loader.cpp:224 calls it
 
 // the reference's vendored BVH library: an INDEPENDENT closest-hit (own traversal loop, own box and triangle arithmetic)
 #include <bvh/bvh.hpp>
@@ -201,5 +205,54 @@ void ref_bvh_closest_hits(const void *tris_in, uint32_t n_tris, const float *ro,
 		t_out[r] = hit ? hit->distance() : 0.0f;
 	}
 }
+
+// ---- the reference's own glTF loader + Model (src/loader.cpp:13-401, src/scene/model.cpp:15-68) and the scene set-up
+// of src/main.cpp:18-33.  Texture-less files only: with textures the loader calls into GL (loader.cpp:48-58, 242-265),
+// whose entry points are not loaded here.  ops: a list of (kind, x, y, z) Model calls applied after LoadGLTF --
+// kind 0 Translate, 1 Rotate, 2 Scale, 3 ApplyModelMatrixToTris -- so the caller can replay src/main.cpp:26-29.
+// Outputs: fat triangles as 25 floats each (v0 v1 v2 n0 n1 n2 uv0 uv1 uv2) + mat index, MaterialGLSL bytes, and the
+// TriangleGLSL bytes of Model::ConvertToSSBOFormat.  Returns the triangle count, or -1 when LoadGLTF returns false.
+int ref_load_gltf(const char *path, const float *ops, uint32_t n_ops, uint32_t max_tris, float *fat25, uint32_t *mat_index,
+                  void *tris64, uint32_t max_mats, void *mats48, uint32_t *n_mats_out)
+{
+	Model model;
+	if (!LoadGLTF(path, model)) return -1;
+	for (uint32_t i = 0; i < n_ops; i++) {
+		const float *o = ops + 4 * i;
+		const glm::vec3 v(o[1], o[2], o[3]);
+		switch ((int) o[0]) {
+		case 0: model.Translate(v); break;
+		case 1: model.Rotate(v); break;
+		case 2: model.Scale(v); break;
+		case 3: model.ApplyModelMatrixToTris(); break;
+		}
+	}
+	if (model.triangles.size > max_tris || model.materials.size > max_mats) return -2;
+	Array<TriangleGLSL> packed = model.ConvertToSSBOFormat();
+	for (uint32_t i = 0; i < model.triangles.size; i++) {
+		const Triangle &t = model.triangles[i];
+		const float rec[25] = {t.v0.x, t.v0.y, t.v0.z, t.v1.x, t.v1.y, t.v1.z, t.v2.x, t.v2.y, t.v2.z,
+		                       t.n0.x, t.n0.y, t.n0.z, t.n1.x, t.n1.y, t.n1.z, t.n2.x, t.n2.y, t.n2.z,
+		                       t.uv0.x, t.uv0.y, t.uv1.x, t.uv1.y, t.uv2.x, t.uv2.y, 0.0f};
+		memcpy(fat25 + 25 * (size_t) i, rec, sizeof rec);
+		mat_index[i] = t.mat_index;
+	}
+	memcpy(tris64, packed._data, (size_t) packed.size * sizeof(TriangleGLSL));
+	memcpy(mats48, model.materials._data, (size_t) model.materials.size * sizeof(MaterialGLSL));
+	*n_mats_out = model.materials.size;
+	return (int) model.triangles.size;
+}
+
+// The two image steps of the loader's textured path on their own (they need no GL): src/loader.cpp:209-214 and :224-226.
+int ref_stbi_load_rgb8(const uint8_t *file, size_t n, uint8_t *out, size_t capacity, int *w, int *h, int *channels)
+{
+	stbi_uc *img = stbi_load_from_memory(file, (int) n, w, h, channels, 3);
+	if (!img) return 1;
+	const size_t bytes = (size_t) *w * *h * 3;
+	if (bytes <= capacity) memcpy(out, img, bytes);
+	stbi_image_free(img);
+	return bytes <= capacity ? 0 : 2;
+}
+int ref_stbir_resize_512(const uint8_t *rgb, int w, int h, uint8_t *out512) { return stbir_resize_uint8(rgb, w, h, 0, out512, 512, 512, 0, 3); }
 
 } // extern "C"

@@ -109,6 +109,22 @@ EXPORTS = {
     "pth_scene_make_atrium": (c_int, [c_void_p, c_uint32, c_uint32]),
     "pth_make_textures": (c_int, [c_uint32, c_uint32, c_void_p]),
     "pth_scene_make_soup": (c_int, [c_void_p, c_uint32, c_uint32, c_float]),
+    "pth_scene_add_packed_materials": (c_uint32, [c_void_p, c_void_p, c_uint32]),
+    "pth_model_create": (c_void_p, []),
+    "pth_model_destroy": (None, [c_void_p]),
+    "pth_last_error": (c_char_p, []),
+    "pth_load_gltf": (c_int, [c_char_p, c_void_p]),
+    "pth_model_translate": (None, [c_void_p, c_void_p]),
+    "pth_model_rotate": (None, [c_void_p, c_void_p]),
+    "pth_model_scale": (None, [c_void_p, c_void_p]),
+    "pth_model_apply_matrix": (None, [c_void_p]),
+    "pth_model_triangle_count": (c_uint32, [c_void_p]),
+    "pth_model_material_count": (c_uint32, [c_void_p]),
+    "pth_model_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pth_model_textures": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint32), c_void_p]),
+    "pth_scene_add_model": (c_int, [c_void_p, c_void_p]),
+    "pth_decode_png_rgb8": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "pth_resize_rgb8_512": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
     "pth_write_ppm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
     "pth_write_pfm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),
@@ -166,6 +182,54 @@ def default_camera() -> np.ndarray:
     return cam
 
 
+class Model:
+    """LoadGLTF + Model (src/loader.h:4, src/scene/model.h:7-29)."""
+
+    def __init__(self, path: str | None = None):
+        self._h = lib().pth_model_create()
+        if path is not None:
+            self.load(path)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().pth_model_destroy(self._h)
+            self._h = None
+
+    def load(self, path: str):
+        if lib().pth_load_gltf(os.fsencode(path), self._h) != 0:
+            raise PtError(lib().pth_last_error().decode())
+        return self
+
+    def translate(self, t):
+        lib().pth_model_translate(self._h, _ptr(np.asarray(t, np.float32)))
+
+    def rotate(self, r):
+        lib().pth_model_rotate(self._h, _ptr(np.asarray(r, np.float32)))
+
+    def scale(self, s):
+        s = np.full(3, s, np.float32) if np.isscalar(s) else np.asarray(s, np.float32)
+        lib().pth_model_scale(self._h, _ptr(s))
+
+    def apply_matrix(self):
+        lib().pth_model_apply_matrix(self._h)
+
+    def arrays(self) -> dict:
+        n, nm = lib().pth_model_triangle_count(self._h), lib().pth_model_material_count(self._h)
+        v, nn, uv = np.zeros((n, 9), np.float32), np.zeros((n, 9), np.float32), np.zeros((n, 6), np.float32)
+        mat, mats = np.zeros(n, np.uint32), np.zeros((nm, 12), np.uint32)
+        lib().pth_model_get(self._h, _ptr(v), _ptr(nn), _ptr(uv), _ptr(mat), _ptr(mats))
+        return {"v": v, "n": nn, "uv": uv, "mat": mat, "materials": mats}
+
+    def textures(self):
+        """(u8 [layers, 512, 512, 3] or None, (wrap_s, wrap_t, mag_filter))"""
+        p, layers, smp = c_void_p(), c_uint32(), np.zeros(3, np.uint32)
+        lib().pth_model_textures(self._h, byref(p), byref(layers), _ptr(smp))
+        tex = None
+        if p.value and layers.value:
+            tex = np.ctypeslib.as_array(ctypes.cast(p, POINTER(c_uint8)), shape=(layers.value, 512, 512, 3)).copy()
+        return tex, tuple(int(x) for x in smp)
+
+
 class Scene:
     """Host-side scene container (src/main.cpp:18-63): triangles, materials, spheres -> six arrays."""
 
@@ -204,6 +268,31 @@ class Scene:
         s = cls()
         _check_host(lib().pth_scene_make_atrium(s._h, detail, seed), "pth_scene_make_atrium")
         return s
+
+    @classmethod
+    def from_gltf(cls, path: str, main_setup: bool = True, spheres: bool = True) -> "Scene":
+        """The scene src/main.cpp:18-55 builds around a model file: LoadGLTF, Translate(0,-2,-6) . Rotate(0,-90 deg,0) .
+        Scale(2) baked into the triangles, the four gold GGX spheres, CalculateBVH, emissive lists.  The texture array
+        and its sampler state are kept on the object (`textures`, `tex_sampler`) for PathTracer.upload_scene."""
+        m = Model(path)
+        if main_setup:
+            m.translate([0.0, -2.0, -6.0])
+            m.rotate([0.0, np.float32(np.deg2rad(np.float32(-90.0))), 0.0])
+            m.scale(2.0)
+            m.apply_matrix()
+        s = cls()
+        s.add_model(m)
+        if spheres:
+            for rough, cx in ((0.0, -1.0), (0.1, -0.4), (0.15, 0.2), (0.2, 0.8)):
+                mi = s.add_material([0, 0, 0], [0.944, 0.776, 0.373], [0, 0, 0], rough, -1, MAT_SPECULAR_METAL)
+                s.add_sphere([cx, 1.0, -5.0], 0.3, mi)
+        s.finalize()
+        s.textures, smp = m.textures()
+        s.tex_sampler = smp if s.textures is not None else None
+        return s
+
+    def add_model(self, model: "Model"):
+        _check_host(lib().pth_scene_add_model(self._h, model._h), "pth_scene_add_model")
 
     def add_material(self, diffuse, specular, le, roughness=0.0, tex_index=-1, mat_type=MAT_LAMBERTIAN) -> int:
         d, s, l = (np.asarray(x, np.float32) for x in (diffuse, specular, le))

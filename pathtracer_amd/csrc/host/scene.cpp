@@ -165,6 +165,15 @@ int pth_scene_add_material(pth_scene *s, const float diffuse[3], const float spe
 	return (int) s->materials.size() - 1;
 }
 
+uint32_t pth_scene_add_packed_materials(pth_scene *s, const void *materials48, uint32_t count)
+{
+	const uint32_t base = (uint32_t) s->materials.size();
+	const PtMaterial *m = (const PtMaterial *) materials48;
+	s->materials.insert(s->materials.end(), m, m + count);
+	s->finalized = false;
+	return base;
+}
+
 int pth_scene_add_sphere(pth_scene *s, const float origin[3], float radius, uint32_t mat_index)
 {
 	PtSphere sp;

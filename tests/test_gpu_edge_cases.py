@@ -158,3 +158,29 @@ def test_main_equivalent_driver(pt, tmp_path):
         c.close()
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert os.path.getsize(ppm) > 256 * 144 * 3
+
+
+def test_main_equivalent_driver_with_a_gltf_model(pt, ol, tmp_path):
+    """The same driver given a model file follows src/main.cpp:18-55 to the letter (LoadGLTF, Translate / Rotate / Scale /
+    ApplyModelMatrixToTris, the four gold spheres): its image equals the Python view's (Scene.from_gltf) and the oracle's."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(pt.__file__), "pt355_main")
+    glb = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gltf", "cornell_lit.glb")
+    ppm, pfm = str(tmp_path / "g.ppm"), str(tmp_path / "g.pfm")
+    out = subprocess.run([exe, "4", "128", "96", ppm, pfm, glb], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    got = pt.read_pfm(pfm, 128, 96)
+    sc = pt.Scene.from_gltf(glb)
+    c = pt.PathTracer(128, 96)
+    try:
+        c.upload_scene(sc, tex_rgb8=sc.textures, tex_sampler=sc.tex_sampler)
+        c.set_camera(pt.default_camera())
+        c.render(0, pt.frame_seeds(0, 4), 5)
+        mine = c.read_framebuffer()
+    finally:
+        c.close()
+    assert np.array_equal(got.view(np.uint32), mine.view(np.uint32))
+    ref, _ = ol.render(ol.scene_from_desc(sc.desc()), pt.default_camera(), 128, 96, pt.frame_seeds(0, 4), bounces=5)
+    assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+    assert mine[..., :3].max() > 0.1    # the emissive-strength ceiling panel lights the box

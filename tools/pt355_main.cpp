@@ -1,10 +1,12 @@
 // pt355_main -- the reference's main() (src/main.cpp:11-121) with the GL upload + dispatch replaced by libpt355.
-// Everything the reference does on the host before the seam keeps its shape: build the model's triangles (here the
-// seeded stand-in mesh, the .glb assets being absent offline), CalculateBVH, append the four gold spheres and their
-// materials (src/main.cpp:44-51), FindEmissive*, upload the six arrays, set the camera of src/main.cpp:67, then one
-// pt_render_frame per displayed frame with FrameData { pcg32_random(), frame_count++, BOUNCE_COUNT, 0 } (src/main.cpp:97).
+// Everything the reference does on the host before the seam keeps its shape: LoadGLTF + the model set-up of
+// src/main.cpp:18-29 when a model file is given (the reference hard-codes res/models/CornellBox_lit.glb, which like all
+// its assets is absent offline; without a file the seeded stand-in mesh is built instead), CalculateBVH, the four gold
+// spheres and their materials (src/main.cpp:44-51), FindEmissive*, upload of the six arrays (and the texture array),
+// the camera of src/main.cpp:67, then one pt_render_frame per displayed frame with FrameData { pcg32_random(),
+// frame_count++, BOUNCE_COUNT, 0 } (src/main.cpp:97).
 // Instead of blitting to a window it writes the tonemapped image (shaders/framebuffer.frag) and the float accumulator.
-//   usage: pt355_main [frames] [width] [height] [out.ppm] [out.pfm]
+//   usage: pt355_main [frames] [width] [height] [out.ppm] [out.pfm] [model.glb]
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -21,11 +23,35 @@ int main(int argc, char **argv)
 	const char *ppm = argc > 4 ? argv[4] : "pt355_main.ppm";
 	const char *pfm = argc > 5 ? argv[5] : nullptr;
 
-	// scene build, src/main.cpp:18-55 (the last argument adds the four gold spheres of :44-51)
+	const char *model_path = argc > 6 ? argv[6] : nullptr;
+
+	// scene build, src/main.cpp:18-55
 	pth_scene *scene = pth_scene_create();
-	if (pth_scene_make_bunny(scene, 59, 69451, 1, PTH_MAT_OREN_NAYAR, 0.175f, 1)) { fprintf(stderr, "scene build failed\n"); return -1; }
+	pth_model *model = nullptr;
+	if (model_path) {
+		model = pth_model_create();
+		if (pth_load_gltf(model_path, model)) { printf("Failed to load model!\n%s\n", pth_last_error()); return -1; } // src/main.cpp:18-23
+		const float t[3] = {0.0f, -2.0f, -6.0f}, r[3] = {0.0f, -90.0f * 0.01745329251994329576923690768489f, 0.0f}, s[3] = {2.0f, 2.0f, 2.0f};
+		pth_model_translate(model, t); // src/main.cpp:26-29
+		pth_model_rotate(model, r);
+		pth_model_scale(model, s);
+		pth_model_apply_matrix(model);
+		pth_scene_add_model(scene, model); // ConvertToSSBOFormat happens in pth_scene_finalize; materials_ssbo = model.materials (:36)
+		const float gold[3] = {0.944f, 0.776f, 0.373f}, zero[3] = {0, 0, 0}, rough[4] = {0.0f, 0.1f, 0.15f, 0.2f}, cx[4] = {-1.0f, -0.4f, 0.2f, 0.8f};
+		for (int i = 0; i < 4; i++) { // src/main.cpp:44-51
+			const int m = pth_scene_add_material(scene, zero, gold, zero, rough[i], -1, PTH_MAT_SPECULAR_METAL);
+			const float o[3] = {cx[i], 1.0f, -5.0f};
+			pth_scene_add_sphere(scene, o, 0.3f, (uint32_t) m);
+		}
+		if (pth_scene_finalize(scene)) { fprintf(stderr, "scene build failed\n"); return -1; }
+	} else if (pth_scene_make_bunny(scene, 59, 69451, 1, PTH_MAT_OREN_NAYAR, 0.175f, 1)) { fprintf(stderr, "scene build failed\n"); return -1; } // last argument: the gold spheres
 	pt_scene_desc desc;
 	pth_scene_desc(scene, &desc);
+	if (model) { // the texture array bound to unit 2, src/main.cpp:83-88, with the sampler state the loader set
+		uint32_t smp[3];
+		pth_model_textures(model, &desc.tex_rgb8, &desc.tex_layers, smp);
+		desc.tex_wrap_s = smp[0]; desc.tex_wrap_t = smp[1]; desc.tex_mag_filter = smp[2];
+	}
 	printf("Calculated BVH for scene, using %u nodes.\n", desc.n_nodes); // src/scene/bvh.cpp:73
 
 	// Display::Display + InitRenderBuffer + the six PushDataToSSBO calls, src/main.cpp:16, 57-63
@@ -62,5 +88,6 @@ int main(int argc, char **argv)
 	       (double) (k.rays_primary + k.rays_shadow + k.rays_bounce) / 1e6, k.ms_trace, k.ms_shade, ppm);
 	pt_destroy(pt);
 	pth_scene_destroy(scene);
+	if (model) pth_model_destroy(model);
 	return 0;
 }
