@@ -318,8 +318,20 @@ PT_DEV float area_triangle(const DevScene &sc, uint32_t i)
 }
 PT_DEV float area_sphere(float r) { return 4.0f * PT_PI * r * r; }
 
-PT_DEV v3 ld3(const float *p, uint32_t i, uint32_t st) { return V(p[i], p[st + i], p[2 * st + i]); }
-PT_DEV void st3(float *p, uint32_t i, uint32_t st, v3 v) { p[i] = v.x; p[st + i] = v.y; p[2 * st + i] = v.z; }
+// queue columns: each slot is read once and written once per stage -> streaming (non-temporal) accesses, see kernels_trace.h
+#ifndef PT_NT_SHADE
+#define PT_NT_SHADE 0
+#endif
+#if PT_NT_SHADE
+#define PT_QLD(p) __builtin_nontemporal_load(p)
+#define PT_QST(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define PT_QLD(p) (*(p))
+#define PT_QST(v, p) (*(p) = (v))
+#endif
+PT_DEV v3 ld3(const float *p, uint32_t i, uint32_t st) { return V(PT_QLD(&p[i]), PT_QLD(&p[st + i]), PT_QLD(&p[2 * st + i])); }
+PT_DEV void st3(float *p, uint32_t i, uint32_t st, v3 v) { PT_QST(v.x, &p[i]); PT_QST(v.y, &p[st + i]); PT_QST(v.z, &p[2 * st + i]); }
+PT_DEV uint4 ldq4(const uint4 *p) { const pt_u32x4 r = PT_QLD((const pt_u32x4 *) p); return make_uint4(r.x, r.y, r.z, r.w); }
 
 // tile-major path -> pixel map shared with pt_partition_pixels(): path p of this rank is pixel
 // (p % 64) of its (p / 64)-th own 8x8 tile; with PT_PARTITION_TILES tile t belongs to rank t % world.
@@ -534,10 +546,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	const uint32_t num_light_sources = sc.n_light_tris + sc.n_light_spheres;
 
 	if (alive) {
-		pixel = a.in.pix[i]; rng = a.in.rng[i]; meta = a.in.meta[i];
+		pixel = PT_QLD(&a.in.pix[i]); rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
 		thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
 		ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
-		const uint4 hrec = a.in.hit[i];
+		const uint4 hrec = ldq4(&a.in.hit[i]);
 		const uint32_t hp = hrec.x, htk = hrec.y;
 		const float hu = __uint_as_float(hrec.z), hv = __uint_as_float(hrec.w);
 		const bool hit_anything = (htk >> 16) != 0u;
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 			// ---- NEE of this bounce, resolved now that the shadow ray is back (fc:970-1006)
 			if (meta & 1u) {
 				v3 direct = V(0.0f, 0.0f, 0.0f);
-				const uint4 srec = a.in.shit[i];
+				const uint4 srec = ldq4(&a.in.shit[i]);
 				const uint32_t sp_ = srec.x, stk = srec.y;
 				if ((stk >> 16) != 0u && (stk >> 16) != 3u) { // kind 3: an any-hit traversal already found an occluder
 					const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 						const float cos_theta_y = dot(sh.n, -srd);
 						if (cos_theta_y > 0.0f) {
 							const v3 P = ld3(a.in.nee, i, st);
-							const float A = a.in.nee[3 * (size_t) st + i], pdf_bsdf = a.in.nee[4 * (size_t) st + i];
+							const float A = PT_QLD(&a.in.nee[3 * (size_t) st + i]), pdf_bsdf = PT_QLD(&a.in.nee[4 * (size_t) st + i]);
 							const float pdf_nee_sa = A / cos_theta_y;
 							const float w_nee = pdf_nee_sa / (pdf_nee_sa + pdf_bsdf);
 							direct = direct + P * w_nee / pdf_nee_sa;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 			}
 			// ---- the bounce ray (fc:1023-1077)
 			const v3 brdf = ld3(a.in.bs, i, st);
-			const float cos_theta_x = a.in.bs[3 * (size_t) st + i], pdf_bsdf_sa = a.in.bs[4 * (size_t) st + i];
+			const float cos_theta_x = PT_QLD(&a.in.bs[3 * (size_t) st + i]), pdf_bsdf_sa = PT_QLD(&a.in.bs[4 * (size_t) st + i]);
 			if (!hit_anything) {
 				col = col + 1.0f * thr * brdf * cos_theta_x * sky_color(sc, rd) / pdf_bsdf_sa; // fc:1027
 				accumulate(a, pixel, col);
@@ -655,8 +667,8 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 		st3(a.out.sray, o, st, x);
 		st3(a.out.sray + 3 * (size_t) st, o, st, shadow_rd);
 		st3(a.out.nee, o, st, P);
-		a.out.nee[3 * (size_t) st + o] = pdf_light_area * squared_dist;
-		a.out.nee[4 * (size_t) st + o] = cos_theta_x / PT_PI;
+		PT_QST(pdf_light_area * squared_dist, &a.out.nee[3 * (size_t) st + o]);
+		PT_QST(cos_theta_x / PT_PI, &a.out.nee[4 * (size_t) st + o]);
 		st3(a.out.nee + 5 * (size_t) st, o, st, y_nee);
 	}
 	const v3 new_ro = x + PT_NORMAL_OFFSET * normal_x; // fc:1009
@@ -667,16 +679,16 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	const v3 new_rd = normalize(mul(inverse_tnb, wi));
 	const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, false);
 
-	a.out.pix[o] = pixel;
-	a.out.rng[o] = rng;
-	a.out.meta[o] = new_meta;
+	PT_QST(pixel, &a.out.pix[o]);
+	PT_QST(rng, &a.out.rng[o]);
+	PT_QST(new_meta, &a.out.meta[o]);
 	st3(a.out.thr, o, st, thr);
 	st3(a.out.col, o, st, col);
 	st3(a.out.ray, o, st, new_ro);
 	st3(a.out.ray + 3 * (size_t) st, o, st, new_rd);
 	st3(a.out.bs, o, st, brdf);
-	a.out.bs[3 * (size_t) st + o] = cos_theta_x;
-	a.out.bs[4 * (size_t) st + o] = pdf_bsdf_sa;
+	PT_QST(cos_theta_x, &a.out.bs[3 * (size_t) st + o]);
+	PT_QST(pdf_bsdf_sa, &a.out.bs[4 * (size_t) st + o]);
 }
 
 // The two estimators the reference keeps commented out at fc:1109-1110, as wavefront stages.  Stage b consumes the

@@ -16,6 +16,21 @@
 #pragma once
 #include "device_math.h"
 
+// streaming accesses to the path queues (each slot is read once and written once per stage)
+// Measured (profiles/r02_nt_experiment.txt): the `nt` forms bypass L1 only and do not keep the blob in L2 any better --
+// k_trace 46.2 -> 47.1 ms, k_shade 23.4 -> 23.7 ms per 64 frames -- so plain accesses stay the default.
+#ifndef PT_NT
+#define PT_NT 0
+#endif
+typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
+#if PT_NT
+#define PT_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define PT_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define PT_NT_LOAD(p) (*(p))
+#define PT_NT_STORE(v, p) (*(p) = (v))
+#endif
+
 #define PT_SHORT_STACK 16
 #define PT_SPILL_STACK 48   // 16 + 48 = 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_BLOCK 256
@@ -226,7 +241,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	// Retire the lane's ray: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax).
 	auto retire = [&]() {
 		if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
-		*hitp = make_uint4(best_prim, best_tk, __float_as_uint(best_u), __float_as_uint(best_v));
+		pt_u32x4 rec;
+		rec.x = best_prim; rec.y = best_tk; rec.z = __float_as_uint(best_u); rec.w = __float_as_uint(best_v);
+		PT_NT_STORE(rec, (pt_u32x4 *) hitp);
 		active = false;
 	};
 
@@ -276,12 +293,14 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 					const uint32_t slot = base + rank;
 					const RaySeg &rs = a.seg[loc_seg];
 					hitp = rs.hit + slot; // where this ray's record goes: kept per lane so that retiring is a store, not a load of the segment table first
-					bool ok = rs.valid ? (rs.valid[slot] & 1u) != 0 : true;
+					// queue columns are read once and streamed: non-temporal, so that they do not push the traversal blob out of
+					// the XCD's 4 MiB L2 (PT_NT below; measured in profiles/r02_*)
+					bool ok = rs.valid ? (PT_NT_LOAD(&rs.valid[slot]) & 1u) != 0 : true;
 					if (ok) {
 						const float *r = rs.ray + slot;
 						const uint32_t st = a.stride;
-						const v3 fro = V(r[0], r[st], r[2 * st]);
-						const v3 frd = V(r[3 * st], r[4 * st], r[5 * st]);
+						const v3 fro = V(PT_NT_LOAD(&r[0]), PT_NT_LOAD(&r[st]), PT_NT_LOAD(&r[2 * st]));
+						const v3 frd = V(PT_NT_LOAD(&r[3 * st]), PT_NT_LOAD(&r[4 * st]), PT_NT_LOAD(&r[5 * st]));
 						// Sphere loop of fc:439-453, hoisted in front of the traversal while the full-precision ray is in
 						// registers.  The loop only compares against tmax, so its outcome is: the LAST sphere attaining the
 						// smallest fp16 t wins iff that t <= the traversal's final tmax -- evaluated when the lane retires.
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 						bool occluded_now = false;
 						if (rs.target && a.shadow_mode != PT_SHADOW_FULL) {
 							const float *tg = rs.target + slot;
-							const v3 y = V(tg[0], tg[st], tg[2 * st]);
+							const v3 y = V(PT_NT_LOAD(&tg[0]), PT_NT_LOAD(&tg[st]), PT_NT_LOAD(&tg[2 * st]));
 							t_kill = fmax_(shadow_kill_component(y.x, fro.x, frd.x),
 							               fmax_(shadow_kill_component(y.y, fro.y, frd.y), shadow_kill_component(y.z, fro.z, frd.z)));
 							if (a.shadow_mode == PT_SHADOW_ANYHIT) {
