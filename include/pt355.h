@@ -180,6 +180,36 @@ int pt_pack_owned(pt_ctx *ctx, void *dst_dev);
 /* src_dev (packed by rank `from_rank` of `world`) -> this context's framebuffer. */
 int pt_unpack_from(pt_ctx *ctx, const void *src_dev, uint32_t from_rank, uint32_t world);
 
+/* ---- Multi-device in one process ("pt_create(device list ...)", "pt_read_framebuffer gathers across
+ * GPUs").  No counterpart in the reference, which is single-GPU: this is what lets a C++ caller shaped like its main()
+ * (src/main.cpp:57-101: upload, set camera, one render call per frame, read the image) use every GPU of a node.
+ * A group holds one pt_ctx per listed device (a device may be listed more than once: "virtual devices", how the
+ * partition and gather logic is tested on one GPU); the scene is replicated, rendering needs no exchange, and the
+ * finished image is gathered onto the first device with peer copies over xGMI.  cfg: width, height, flags, max_batch,
+ * pipelines are used; device / partition / rank / world are set per member.  One group per host thread. */
+#define PT_GROUP_TILES   0u /* 8x8 tiles dealt round-robin over the members; image bit-identical to one device's */
+#define PT_GROUP_SAMPLES 1u /* frame f -> member f % n over the full image; gather = sum_i (n_i / N) * mean_i (agrees with the
+                               sequential running mean to ~1e-6 relative: the summation order differs) */
+typedef struct pt_group pt_group;
+int pt_group_create(const pt_config *cfg, const int32_t *devices, uint32_t n_devices, uint32_t mode, pt_group **out);
+int pt_group_destroy(pt_group *g);
+const char *pt_group_last_error(const pt_group *g); /* g may be NULL: error of the last failed pt_group_create */
+uint32_t pt_group_size(const pt_group *g);
+pt_ctx *pt_group_member(pt_group *g, uint32_t i);   /* the member's own context, e.g. for pt_get_counters per device */
+int pt_group_upload_scene(pt_group *g, const pt_scene_desc *scene);
+int pt_group_set_camera(pt_group *g, const float cam[12]);
+int pt_group_set_estimator(pt_group *g, uint32_t estimator);
+/* frames first_frame.. with seeds[i] per frame, like pt_render; asynchronous on every member */
+int pt_group_render(pt_group *g, uint32_t first_frame, uint32_t n_frames, const uint32_t *seeds, uint32_t bounces);
+int pt_group_sync(pt_group *g);
+int pt_group_clear(pt_group *g);
+/* gathers, then hands out the device address (on the first device) of the full RGBA32F image; valid until the next
+ * group call */
+int pt_group_gather(pt_group *g, void **image_dev);
+/* pt_read_framebuffer across the group: gather + copy to the host */
+int pt_group_read_framebuffer(pt_group *g, float *rgba, size_t n_floats);
+int pt_group_get_counters(pt_group *g, pt_counters *out); /* sums over the members */
+
 /* Numerics self-test hook: evaluates one primitive of the arithmetic contract on the device
  * (op codes as in oracle/oracle.h) so tests can pin device min/max/div/sqrt/fp16/transcendentals. */
 int pt_debug_eval(pt_ctx *ctx, int op, const float *a, const float *b, uint32_t n, float *out);

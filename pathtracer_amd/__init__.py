@@ -84,6 +84,20 @@ EXPORTS = {
     "pt_debug_read_queue": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32)]),
     "pt_build_bvh_device": (c_int, [c_void_p, c_void_p, c_uint32, c_uint32, c_void_p, POINTER(c_uint32), c_void_p, POINTER(c_float)]),
     "pt_scene_finalize_device": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_float)]),
+    "pt_group_create": (c_int, [POINTER(pt_config), c_void_p, c_uint32, c_uint32, POINTER(c_void_p)]),
+    "pt_group_destroy": (c_int, [c_void_p]),
+    "pt_group_last_error": (c_char_p, [c_void_p]),
+    "pt_group_size": (c_uint32, [c_void_p]),
+    "pt_group_member": (c_void_p, [c_void_p, c_uint32]),
+    "pt_group_upload_scene": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
+    "pt_group_set_camera": (c_int, [c_void_p, c_void_p]),
+    "pt_group_set_estimator": (c_int, [c_void_p, c_uint32]),
+    "pt_group_render": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p, c_uint32]),
+    "pt_group_sync": (c_int, [c_void_p]),
+    "pt_group_clear": (c_int, [c_void_p]),
+    "pt_group_gather": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "pt_group_read_framebuffer": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "pt_group_get_counters": (c_int, [c_void_p, POINTER(pt_counters)]),
     # host side
     "pth_pack_half2x16": (c_uint32, [c_float, c_float]),
     "pth_oct_encode": (None, [c_void_p, c_void_p]),
@@ -494,6 +508,69 @@ class PathTracer:
         out = np.empty_like(a)
         self._check(lib().pt_debug_eval(self._h, op, _ptr(a), _ptr(bb), a.size, _ptr(out)), "pt_debug_eval")
         return out
+
+
+PT_GROUP_TILES, PT_GROUP_SAMPLES = 0, 1
+
+
+class Group:
+    """pt_group: several devices (or several virtual devices on one) behind one handle, in one process."""
+
+    def __init__(self, width: int, height: int, devices, mode: int = PT_GROUP_TILES, flags: int = 0, max_batch: int = 0):
+        L = lib()
+        cfg = pt_config(width=width, height=height, flags=flags, max_batch=max_batch)
+        dev = np.ascontiguousarray(devices, np.int32)
+        h = c_void_p()
+        if L.pt_group_create(byref(cfg), _ptr(dev), dev.size, mode, byref(h)) != 0:
+            raise PtError(f"pt_group_create: {L.pt_group_last_error(None).decode()}")
+        self._h, self.width, self.height, self.mode = h, width, height, mode
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PtError(f"{what}: {lib().pt_group_last_error(self._h).decode()} (code {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pt_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def upload_scene(self, scene, tex_rgb8=None, tex_sampler=None):
+        d = scene.desc() if isinstance(scene, Scene) else scene
+        self._keep = [scene]
+        if tex_rgb8 is not None:
+            tex = np.ascontiguousarray(tex_rgb8, np.uint8)
+            d.tex_rgb8, d.tex_layers = tex.ctypes.data, tex.shape[0]
+            self._keep.append(tex)
+        if tex_sampler is not None:
+            d.tex_wrap_s, d.tex_wrap_t, d.tex_mag_filter = tex_sampler
+        self._check(lib().pt_group_upload_scene(self._h, byref(d)), "pt_group_upload_scene")
+
+    def set_camera(self, cam12):
+        cam = np.ascontiguousarray(cam12, np.float32).reshape(12)
+        self._check(lib().pt_group_set_camera(self._h, _ptr(cam)), "pt_group_set_camera")
+
+    def render(self, first_frame: int, seeds, bounces: int = 5):
+        seeds = np.ascontiguousarray(seeds, np.uint32)
+        self._check(lib().pt_group_render(self._h, first_frame, seeds.size, _ptr(seeds), bounces), "pt_group_render")
+
+    def sync(self):
+        self._check(lib().pt_group_sync(self._h), "pt_group_sync")
+
+    def clear(self):
+        self._check(lib().pt_group_clear(self._h), "pt_group_clear")
+
+    def read_framebuffer(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(lib().pt_group_read_framebuffer(self._h, _ptr(out), out.size), "pt_group_read_framebuffer")
+        return out
+
+    def counters(self) -> dict:
+        c = pt_counters()
+        self._check(lib().pt_group_get_counters(self._h, byref(c)), "pt_group_get_counters")
+        return c.as_dict()
 
 
 def make_textures(layers: int = 6, seed: int = 1) -> np.ndarray:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|char|pth_scene|pth_model)\s*\*?\s*(pth?_[a-z0-9_]+)\s*\(", re.M)
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|uint32_t|uint64_t|char|pth_scene|pth_model|pt_ctx)\s*\*?\s*(pth?_[a-z0-9_]+)\s*\(", re.M)
 
 
 def _declared():

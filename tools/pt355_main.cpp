@@ -6,7 +6,9 @@
 // the camera of src/main.cpp:67, then one pt_render_frame per displayed frame with FrameData { pcg32_random(),
 // frame_count++, BOUNCE_COUNT, 0 } (src/main.cpp:97).
 // Instead of blitting to a window it writes the tonemapped image (shaders/framebuffer.frag) and the float accumulator.
-//   usage: pt355_main [frames] [width] [height] [out.ppm] [out.pfm] [model.glb]
+//   usage: pt355_main [frames] [width] [height] [out.ppm] [out.pfm] [model.glb | -] [devices, e.g. 0,1,2,3] [tiles | samples]
+// With a device list the same sequence runs on a pt_group: the scene is replicated, the image partitioned over the
+// devices (8x8 tiles by default) and gathered onto the first one for the read-back.
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +25,11 @@ int main(int argc, char **argv)
 	const char *ppm = argc > 4 ? argv[4] : "pt355_main.ppm";
 	const char *pfm = argc > 5 ? argv[5] : nullptr;
 
-	const char *model_path = argc > 6 ? argv[6] : nullptr;
+	const char *model_path = argc > 6 && argv[6][0] != '-' ? argv[6] : nullptr;
+	std::vector<int32_t> devices;
+	if (argc > 7)
+		for (const char *p = argv[7]; *p;) { devices.push_back((int32_t) strtol(p, (char **) &p, 10)); if (*p == ',') p++; }
+	const uint32_t group_mode = argc > 8 && argv[8][0] == 's' ? PT_GROUP_SAMPLES : PT_GROUP_TILES;
 
 	// scene build, src/main.cpp:18-55
 	pth_scene *scene = pth_scene_create();
@@ -57,26 +63,46 @@ int main(int argc, char **argv)
 	// Display::Display + InitRenderBuffer + the six PushDataToSSBO calls, src/main.cpp:16, 57-63
 	pt_config cfg = {};
 	cfg.width = width; cfg.height = height; cfg.partition = PT_PARTITION_FULL;
+	const float origin[3] = {0, 0, 0}, forward[3] = {0, 0, -1}, right[3] = {1, 0, 0};
+	float cam_glsl[12];
+	pth_pack_camera(origin, forward, right, 0.005f, 0.05f, cam_glsl);
+	std::vector<uint32_t> seed(frames);
+	pth_frame_seeds(0, frames, seed.data()); // successive pcg32_random() of the default global stream
+	std::vector<float> rgba((size_t) width * height * 4);
+	if (!devices.empty()) {
+		// the same sequence on several devices at once (no counterpart in the reference)
+		pt_group *grp = nullptr;
+		if (pt_group_create(&cfg, devices.data(), (uint32_t) devices.size(), group_mode, &grp) != PT_OK) { fprintf(stderr, "%s\n", pt_group_last_error(nullptr)); return -1; }
+		if (pt_group_upload_scene(grp, &desc) != PT_OK || pt_group_set_camera(grp, cam_glsl) != PT_OK) { fprintf(stderr, "%s\n", pt_group_last_error(grp)); return -1; }
+		if (pt_group_render(grp, 0, frames, seed.data(), BOUNCE_COUNT) != PT_OK) { fprintf(stderr, "%s\n", pt_group_last_error(grp)); return -1; }
+		if (pt_group_read_framebuffer(grp, rgba.data(), rgba.size()) != PT_OK) { fprintf(stderr, "%s\n", pt_group_last_error(grp)); return -1; }
+		pt_counters k;
+		pt_group_get_counters(grp, &k);
+		std::vector<uint8_t> rgb8((size_t) width * height * 3);
+		pth_tonemap_rgb8(rgba.data(), width, height, rgb8.data());
+		if (pth_write_ppm(ppm, rgb8.data(), width, height)) { fprintf(stderr, "cannot write %s\n", ppm); return -1; }
+		if (pfm && pth_write_pfm(pfm, rgba.data(), width, height)) { fprintf(stderr, "cannot write %s\n", pfm); return -1; }
+		printf("%u frames of %ux%u on %zu devices (%s): %.1f M rays -> %s\n", frames, width, height, devices.size(), group_mode == PT_GROUP_TILES ? "tiles" : "samples",
+		       (double) (k.rays_primary + k.rays_shadow + k.rays_bounce) / 1e6, ppm);
+		pt_group_destroy(grp);
+		pth_scene_destroy(scene);
+		if (model) pth_model_destroy(model);
+		return 0;
+	}
 	pt_ctx *pt = nullptr;
 	if (pt_create(&cfg, &pt) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error(nullptr)); return -1; }
 	if (pt_upload_scene(pt, &desc) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error(pt)); return -1; }
 
 	// Camera cam(origin 0, forward -z, right +x, 0.005, 0.05), src/main.cpp:67; uploaded when frame_count == 0 (:90-94)
-	const float origin[3] = {0, 0, 0}, forward[3] = {0, 0, -1}, right[3] = {1, 0, 0};
-	float cam_glsl[12];
-	pth_pack_camera(origin, forward, right, 0.005f, 0.05f, cam_glsl);
 	pt_set_camera(pt, cam_glsl);
 
 	// the frame loop, src/main.cpp:69-101: one sample per pixel per frame, blended into the running mean
-	std::vector<uint32_t> seed(frames);
-	pth_frame_seeds(0, frames, seed.data()); // successive pcg32_random() of the default global stream
 	for (uint32_t frame_count = 0; frame_count < frames; frame_count++) {
 		const uint32_t frame_data[4] = {seed[frame_count], frame_count, BOUNCE_COUNT, 0};
 		if (pt_render_frame(pt, frame_data) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error(pt)); return -1; }
 	}
 
 	// the blit, src/main.cpp:103-118 + shaders/framebuffer.frag
-	std::vector<float> rgba((size_t) width * height * 4);
 	if (pt_read_framebuffer(pt, rgba.data(), rgba.size()) != PT_OK) { fprintf(stderr, "%s\n", pt_last_error(pt)); return -1; }
 	std::vector<uint8_t> rgb8((size_t) width * height * 3);
 	pth_tonemap_rgb8(rgba.data(), width, height, rgb8.data());
