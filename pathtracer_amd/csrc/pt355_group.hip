@@ -78,17 +78,19 @@ int pt_group_destroy(pt_group *g)
 {
 	if (!g) return PT_OK;
 	for (size_t i = 0; i < g->member.size(); i++) {
-		if (g->member[i]) pt_sync(g->member[i]);
-		if (i < g->device.size()) hipSetDevice(g->device[i]);
+		if (!g->member[i]) continue; // a member that was never created (failed pt_group_create) owns nothing, and its device may not exist
+		pt_sync(g->member[i]);
+		hipSetDevice(g->device[i]);
 		if (i < g->staging_src.size() && g->staging_src[i]) hipFree(g->staging_src[i]);
 		if (i < g->copy_stream.size() && g->copy_stream[i]) hipStreamDestroy(g->copy_stream[i]);
 	}
-	if (!g->device.empty()) hipSetDevice(g->device[0]);
+	if (!g->member.empty() && g->member[0]) hipSetDevice(g->device[0]);
 	for (void *p : g->staging_dst) if (p) hipFree(p);
 	if (g->gathered) hipFree(g->gathered);
 	if (g->stream0) hipStreamDestroy(g->stream0);
 	for (pt_ctx *c : g->member) if (c) pt_destroy(c);
 	delete g;
+	(void) hipGetLastError(); // nothing above may leave a sticky error for the thread's next launch check
 	return PT_OK;
 }
 
