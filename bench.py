@@ -47,6 +47,15 @@ def make_scene(pt, name):
         return pt.Scene.atrium(detail=4, seed=1)
     if name == "cornell":    # configs[0]
         return pt.Scene.cornell()
+    if name == "atrium_gltf":  # configs[3] through the glTF path: the atrium written out as a .glb, then LoadGLTF + src/main.cpp's set-up
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_scene_glb
+        path = os.path.join(tempfile.gettempdir(), f"pt355_atrium_{os.getpid()}.glb")
+        make_scene_glb.write_scene_glb(pt.Scene.atrium(detail=4, seed=1), path, pt.make_textures(6, 1))
+        sc = pt.Scene.from_gltf(path)
+        os.unlink(path)
+        return sc
     if name.endswith((".glb", ".gltf")) and hasattr(pt.Scene, "from_gltf"):
         return pt.Scene.from_gltf(name)  # the reference's LoadGLTF + the scene set-up of src/main.cpp:19-63
     raise SystemExit(f"unknown scene {name}")

@@ -61,6 +61,9 @@ int pth_scene_add_sphere(pth_scene *s, const float origin[3], float radius, uint
 /* count "fat" triangles (src/scene/triangle.hpp:8-24): v 9 floats, n 9 floats, uv 6 floats (uv may be NULL) */
 int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const float *uv, const uint32_t *mat,
                             uint32_t count);
+/* the fat triangles added so far, in insertion order (any pointer may be NULL) -- e.g. to write a scene out as glTF */
+uint32_t pth_scene_fat_count(const pth_scene *s);
+int pth_scene_get_fat(const pth_scene *s, float *v9, float *n9, float *uv6, uint32_t *mat);
 /* Model::ConvertToSSBOFormat + CalculateBVH + FindEmissive* (src/main.cpp:31-55) */
 int pth_scene_finalize(pth_scene *s);
 /* Same, with the BVH built by `build` instead of CalculateBVH: build(tris, n, nodes_out [2n+1 nodes of room],

@@ -114,6 +114,8 @@ EXPORTS = {
     "pth_scene_add_material": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int]),
     "pth_scene_add_sphere": (c_int, [c_void_p, c_void_p, c_float, c_uint32]),
     "pth_scene_add_triangles": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
+    "pth_scene_fat_count": (c_uint32, [c_void_p]),
+    "pth_scene_get_fat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pth_scene_finalize": (c_int, [c_void_p]),
     "pth_scene_finalize_with": (c_int, [c_void_p, c_void_p, c_void_p]),
     "pth_scene_desc": (c_int, [c_void_p, POINTER(pt_scene_desc)]),
@@ -326,6 +328,13 @@ class Scene:
 
     def finalize(self):
         _check_host(lib().pth_scene_finalize(self._h), "pth_scene_finalize")
+
+    def fat_triangles(self) -> dict:
+        """The triangles as they were added (v [n,9], n [n,9], uv [n,6], mat [n]), before packing and BVH order."""
+        n = lib().pth_scene_fat_count(self._h)
+        v, nn, uv, mat = np.zeros((n, 9), np.float32), np.zeros((n, 9), np.float32), np.zeros((n, 6), np.float32), np.zeros(n, np.uint32)
+        lib().pth_scene_get_fat(self._h, _ptr(v), _ptr(nn), _ptr(uv), _ptr(mat))
+        return {"v": v, "n": nn, "uv": uv, "mat": mat}
 
     def desc(self) -> pt_scene_desc:
         d = pt_scene_desc()

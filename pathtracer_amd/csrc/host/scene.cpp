@@ -196,6 +196,17 @@ int pth_scene_add_triangles(pth_scene *s, const float *v, const float *n, const 
 	return PT_OK;
 }
 
+uint32_t pth_scene_fat_count(const pth_scene *s) { return (uint32_t) s->mat.size(); }
+int pth_scene_get_fat(const pth_scene *s, float *v9, float *n9, float *uv6, uint32_t *mat)
+{
+	const size_t n = s->mat.size();
+	if (v9) memcpy(v9, s->v.data(), n * 36);
+	if (n9) memcpy(n9, s->n.data(), n * 36);
+	if (uv6) memcpy(uv6, s->uv.data(), n * 24);
+	if (mat) memcpy(mat, s->mat.data(), n * 4);
+	return PT_OK;
+}
+
 static uint32_t reference_builder(const void *tris, uint32_t n, void *nodes_out, void *sorted_out, void *)
 {
 	return pth_build_bvh(tris, n, nodes_out, sorted_out);
