@@ -18,7 +18,6 @@
 #define PT_EST_MIS 0u   // estimator_path_tracing_mis,  fc:874-1081 (the live one, fc:1111)
 #define PT_EST_NEE 1u   // estimator_path_tracing_nee,  fc:725-867
 #define PT_EST_BRDF 2u  // estimator_path_tracing_BRDF, fc:647-693
-#define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
 
 // columns of one path queue; every array has `stride` entries per component
 struct PathQ {
@@ -333,18 +332,6 @@ PT_DEV v3 ld3(const float *p, uint32_t i, uint32_t st) { return V(PT_QLD(&p[i]),
 PT_DEV void st3(float *p, uint32_t i, uint32_t st, v3 v) { PT_QST(v.x, &p[i]); PT_QST(v.y, &p[st + i]); PT_QST(v.z, &p[2 * st + i]); }
 PT_DEV uint4 ldq4(const uint4 *p) { const pt_u32x4 r = PT_QLD((const pt_u32x4 *) p); return make_uint4(r.x, r.y, r.z, r.w); }
 
-// tile-major path -> pixel map shared with pt_partition_pixels(): path p of this rank is pixel
-// (p % 64) of its (p / 64)-th own 8x8 tile; with PT_PARTITION_TILES tile t belongs to rank t % world.
-PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
-{
-	const uint32_t tiles_x = width >> 3;
-	uint32_t tile = p >> 6;
-	if (partition == 0u && world > 1u) tile = tile * world + rank;
-	const uint32_t in = p & 63u;
-	const uint32_t x = (tile % tiles_x) * 8u + (in & 7u), y = (tile / tiles_x) * 8u + (in >> 3);
-	return y * width + x;
-}
-
 // Light sampling shared by the MIS and NEE estimators (fc:926-956 == fc:765-808): one raw draw picks the light, two
 // rand draws the point on it.
 struct LightPick { v3 y, le; float area; };
@@ -460,28 +447,9 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_raygen(ShadeArgs a)
 	}
 	if (p >= n_total) return;
 	if (no_rays) { a.sample[p] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); return; }
-	const uint32_t fslot = p / a.n_paths_frame;
-	const uint32_t pixel = path_pixel(p - fslot * a.n_paths_frame, a.width, a.partition, a.rank, a.world);
-	const uint32_t px = pixel % a.width, py = pixel / a.width;
-	uint32_t rng = seed3(px, py, a.seeds[fslot]);
-
-	const v3 cam_origin = V(a.cam[0], a.cam[1], a.cam[2]);
-	const v3 cam_forward = V(a.cam[4], a.cam[5], a.cam[6]);
-	const v3 cam_right = V(a.cam[8], a.cam[9], a.cam[10]);
-	const float sw = (float) a.width, sh = (float) a.height;
-	const float grid_height = 2.0f;
-	const float grid_width = grid_height * sw / sh;
-	const v3 cam_up = normalize(cross(cam_right, cam_forward));
-	const v3 grid_x = cam_right * grid_width;
-	const v3 grid_y = cam_up * grid_height;
-	v3 grid_origin = (cam_origin - (grid_x * 0.5f)) - (grid_y * 0.5f);
-	grid_origin = grid_origin + 2.0f * cam_forward;
-	const float ox = rnd(rng) - 0.5f;
-	const float oy = rnd(rng) - 0.5f;
-	const float u = ((float) (int) px + ox) / sw;
-	const float v = ((float) (int) py + oy) / sh;
-	const v3 point_on_grid = (grid_origin + u * grid_x) + v * grid_y;
-	const v3 rd = normalize(point_on_grid - cam_origin);
+	v3 cam_origin, rd;
+	uint32_t rng;
+	primary_ray(a, p, &cam_origin, &rd, &rng);
 
 	const uint32_t st = a.stride;
 	const uint32_t region = p / a.per_region;
@@ -523,12 +491,20 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_resolve(ShadeArgs a)
 
 // One shading stage.  stage 0 consumes the primary hit (fc:880-896); stage k >= 1 consumes the shadow and
 // bounce hits of bounce k (fc:970-1077) and, unless k == bounces, emits bounce k+1 (fc:901-968, 1009-1017).
+// PRIMARY = true is stage 0 of the fused primary stage: slot i IS path i of the batch (dense, no regions), its hit was
+// written by k_trace<.., GEN>, and ray + RNG state are generated again by primary_ray instead of being read -- no
+// k_raygen launch, and neither kernel touches the 52 bytes per path that k_raygen would have written.
+template <bool PRIMARY>
 __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(ShadeArgs a)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t in_region = blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size
-	const uint32_t n_in = a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
+	const uint32_t in_region = PRIMARY ? 0u : blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size
+	const uint32_t n_in = PRIMARY ? a.n_batch * a.n_paths_frame : a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
 	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
+	if (PRIMARY && i == 0) { // what k_raygen counts
+		atomicAdd(&a.ctl->paths, (unsigned long long) n_in);
+		atomicAdd(&a.ctl->rays_primary, (unsigned long long) n_in);
+	}
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
 	// a block wholly past its region's fill has nothing to read and nothing to claim (the grid covers every slot of
@@ -546,15 +522,21 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	const uint32_t num_light_sources = sc.n_light_tris + sc.n_light_spheres;
 
 	if (alive) {
-		pixel = PT_QLD(&a.in.pix[i]); rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
-		thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
-		ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
+		if (PRIMARY) {
+			pixel = i;
+			primary_ray(a, i, &ro, &rd, &rng);
+			thr = V(1.0f, 1.0f, 1.0f);
+		} else {
+			pixel = PT_QLD(&a.in.pix[i]); rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
+			thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
+			ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
+		}
 		const uint4 hrec = ldq4(&a.in.hit[i]);
 		const uint32_t hp = hrec.x, htk = hrec.y;
 		const float hu = __uint_as_float(hrec.z), hv = __uint_as_float(hrec.w);
 		const bool hit_anything = (htk >> 16) != 0u;
 
-		if (a.stage == 0) {
+		if (PRIMARY || a.stage == 0) {
 			if (!hit_anything) {
 				col = sky_color(sc, rd) * 1.0f; // fc:884
 				accumulate(a, pixel, col);
@@ -627,7 +609,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 			}
 		}
 	}
-	if (a.stage == 0 && a.bounces == 0 && alive) { // frame_data.z == 0: the loop at fc:899 never runs
+	if ((PRIMARY || a.stage == 0) && a.bounces == 0 && alive) { // frame_data.z == 0: the loop at fc:899 never runs
 		accumulate(a, pixel, col);
 		alive = false;
 	}

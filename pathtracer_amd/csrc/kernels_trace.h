@@ -44,6 +44,53 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_SHARDS 64
 #define PT_SHARD_STRIDE 32   // u32 words between two counters = 128 bytes
 
+#define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
+
+// tile-major path -> pixel map shared with pt_partition_pixels(): path p of this rank is pixel
+// (p % 64) of its (p / 64)-th own 8x8 tile; with PT_PARTITION_TILES tile t belongs to rank t % world.
+PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
+{
+	const uint32_t tiles_x = width >> 3;
+	uint32_t tile = p >> 6;
+	if (partition == 0u && world > 1u) tile = tile * world + rank;
+	const uint32_t in = p & 63u;
+	const uint32_t x = (tile % tiles_x) * 8u + (in & 7u), y = (tile / tiles_x) * 8u + (in >> 3);
+	return y * width + x;
+}
+
+// main() + render_function(), fc:1088-1122: seed, pixel jitter, pinhole ray of path p of a batch (frame slot
+// p / n_paths_frame, path-in-frame p % n_paths_frame).  ONE function for every kernel that needs the camera ray -- the
+// stand-alone k_raygen, and the fused primary stage where k_trace generates the ray at refill and k_shade generates it
+// again instead of both reading it from HBM -- so all of them get the same bits.  A: any argument block with the
+// members cam, width, height, n_paths_frame, partition, rank, world, seeds.
+template <typename A>
+PT_DEV void primary_ray(const A &a, uint32_t p, v3 *ro_out, v3 *rd_out, uint32_t *rng_out)
+{
+	const uint32_t fslot = p / a.n_paths_frame;
+	const uint32_t pixel = path_pixel(p - fslot * a.n_paths_frame, a.width, a.partition, a.rank, a.world);
+	const uint32_t px = pixel % a.width, py = pixel / a.width;
+	uint32_t rng = seed3(px, py, a.seeds[fslot]);
+	const v3 cam_origin = V(a.cam[0], a.cam[1], a.cam[2]);
+	const v3 cam_forward = V(a.cam[4], a.cam[5], a.cam[6]);
+	const v3 cam_right = V(a.cam[8], a.cam[9], a.cam[10]);
+	const float sw = (float) a.width, sh = (float) a.height;
+	const float grid_height = 2.0f;
+	const float grid_width = grid_height * sw / sh;
+	const v3 cam_up = normalize(cross(cam_right, cam_forward));
+	const v3 grid_x = cam_right * grid_width;
+	const v3 grid_y = cam_up * grid_height;
+	v3 grid_origin = (cam_origin - (grid_x * 0.5f)) - (grid_y * 0.5f);
+	grid_origin = grid_origin + 2.0f * cam_forward;
+	const float ox = rnd(rng) - 0.5f;
+	const float oy = rnd(rng) - 0.5f;
+	const float u = ((float) (int) px + ox) / sw;
+	const float v = ((float) (int) py + oy) / sh;
+	const v3 point_on_grid = (grid_origin + u * grid_x) + v * grid_y;
+	*ro_out = cam_origin;
+	*rd_out = normalize(point_on_grid - cam_origin);
+	*rng_out = rng;
+}
+
 struct DevScene {
 	// Traversal blob (pt355.hip build_traversal_blob), addressed by 32-bit byte offsets:
 	//   record of an inner node, 64 B: (lo0.xyz, link0) (hi0.xyz, bytes0) (lo1.xyz, link1) (hi1.xyz, bytes1) -- the bounds of
@@ -98,6 +145,10 @@ struct TraceArgs {
 	DevCtl *ctl;
 	uint32_t *zero_on_entry;   // optional: region counters of the queue the next shading kernel fills, cleared by block 0
 	uint32_t *spill;           // [gridDim.x * PT_TRACE_WAVES][PT_SPILL_STACK][64]
+	// k_trace<.., GEN = true> only (the fused primary stage): slot s IS path s of the batch and its ray is generated here
+	float cam[12];
+	uint32_t width, height, n_paths_frame, partition, rank, world;
+	uint32_t seeds[PT_MAX_BATCH];
 };
 
 PT_DEV void box_pair_test(float4 lo, float4 hi, v3 ro, v3 inv, float tmax, float *entry, float *exit_)
@@ -173,7 +224,7 @@ PT_DEV float shadow_kill_component(float y, float ro, float rd)
 // descend/push/pop decision never depended on them (the stack holds record offsets only).
 // cur, tri, tri_end and the stack entries are byte offsets into the traversal blob: the address of either mode is
 // one select away, and no index is converted or range-checked here (pt_upload_scene proved every link).
-template <bool COUNT>
+template <bool COUNT, bool GEN>
 __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 {
 	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK][64];
@@ -295,12 +346,18 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 					hitp = rs.hit + slot; // where this ray's record goes: kept per lane so that retiring is a store, not a load of the segment table first
 					// queue columns are read once and streamed: non-temporal, so that they do not push the traversal blob out of
 					// the XCD's 4 MiB L2 (PT_NT below; measured in profiles/r02_*)
-					bool ok = rs.valid ? (PT_NT_LOAD(&rs.valid[slot]) & 1u) != 0 : true;
+					bool ok = (!GEN && rs.valid) ? (PT_NT_LOAD(&rs.valid[slot]) & 1u) != 0 : true;
 					if (ok) {
-						const float *r = rs.ray + slot;
 						const uint32_t st = a.stride;
-						const v3 fro = V(PT_NT_LOAD(&r[0]), PT_NT_LOAD(&r[st]), PT_NT_LOAD(&r[2 * st]));
-						const v3 frd = V(PT_NT_LOAD(&r[3 * st]), PT_NT_LOAD(&r[4 * st]), PT_NT_LOAD(&r[5 * st]));
+						v3 fro, frd;
+						if (GEN) {
+							uint32_t rng_unused;
+							primary_ray(a, slot, &fro, &frd, &rng_unused); // the camera ray of path `slot`: nothing to read
+						} else {
+							const float *r = rs.ray + slot;
+							fro = V(PT_NT_LOAD(&r[0]), PT_NT_LOAD(&r[st]), PT_NT_LOAD(&r[2 * st]));
+							frd = V(PT_NT_LOAD(&r[3 * st]), PT_NT_LOAD(&r[4 * st]), PT_NT_LOAD(&r[5 * st]));
+						}
 						// Sphere loop of fc:439-453, hoisted in front of the traversal while the full-precision ray is in
 						// registers.  The loop only compares against tmax, so its outcome is: the LAST sphere attaining the
 						// smallest fp16 t wins iff that t <= the traversal's final tmax -- evaluated when the lane retires.
@@ -318,7 +375,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 						// shadow rays: how early may the traversal stop?
 						t_kill = -__builtin_inff();
 						bool occluded_now = false;
-						if (rs.target && a.shadow_mode != PT_SHADOW_FULL) {
+						if (!GEN && rs.target && a.shadow_mode != PT_SHADOW_FULL) {
 							const float *tg = rs.target + slot;
 							const v3 y = V(PT_NT_LOAD(&tg[0]), PT_NT_LOAD(&tg[st]), PT_NT_LOAD(&tg[2 * st]));
 							t_kill = fmax_(shadow_kill_component(y.x, fro.x, frd.x),

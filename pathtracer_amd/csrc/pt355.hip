@@ -70,6 +70,7 @@ struct pt_ctx {
 	std::string err;
 	int n_cu = 0;
 	int trace_grid = 0;
+	bool fused_primary = true;      // MIS: k_raygen folded into the primary k_trace / k_shade (PT355_FUSED_PRIMARY=0 turns it off for A/B runs)
 	uint32_t refill_threshold = 32; // idle lanes that trigger a refill: sweep 8..64 on the bench scene peaks at 32 (a refill costs ~3 loop iterations)
 
 	// scene
@@ -246,13 +247,18 @@ void carve_queue(PathQ &q, char *&p, uint32_t stride)
 }
 const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
 
-int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta)
+int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = false)
 {
 	const bool timed = begin_timed(c, pp, 0);
-	if (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL)
-		hipLaunchKernelGGL(k_trace<true>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
+	const bool count = (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL) != 0;
+	const dim3 grid(c->trace_grid), block(PT_TRACE_BLOCK);
+	if (gen_primary) {
+		if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, pp.stream, ta);
+		else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, pp.stream, ta);
+	} else if (count)
+		hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, pp.stream, ta);
 	else
-		hipLaunchKernelGGL(k_trace<false>, dim3(c->trace_grid), dim3(PT_TRACE_BLOCK), 0, pp.stream, ta);
+		hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, pp.stream, ta);
 	end_timed(c, pp, timed);
 	c->trace_launches++;
 	HIP_TRY(c, hipGetLastError());
@@ -340,12 +346,13 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	c->stream = c->pipe[0].stream;
 
 	int blocks_per_cu = 0;
-	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false>, PT_TRACE_BLOCK, 0));
+	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false, false>, PT_TRACE_BLOCK, 0));
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
 	// tuning knobs for experiments (tools/exp_*.py), read once per pt_create; defaults are the measured optimum (DESIGN.md
-	// section 7): PT355_PIPES (1..4), PT355_TRACE_BLOCKS_PER_CU, PT355_REFILL (1..64), PT355_BATCH (1..32).  None changes results.
+	// section 7): PT355_PIPES (1..4), PT355_TRACE_BLOCKS_PER_CU, PT355_REFILL (1..64), PT355_BATCH (1..32), PT355_FUSED_PRIMARY (0/1).  None changes results.
 	if (const char *e = getenv("PT355_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= blocks_per_cu) blocks_per_cu = v; }
+	if (const char *e = getenv("PT355_FUSED_PRIMARY")) c->fused_primary = atoi(e) != 0;
 	if (const char *e = getenv("PT355_REFILL")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_threshold = (uint32_t) v; }
 	c->trace_grid = c->n_cu * blocks_per_cu;
 
@@ -633,17 +640,35 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	const dim3 sgrid(c->stride / PT_SHADE_BLOCK);
 
 	sa.out = pp.q[0];
-	const bool timed_ = begin_timed(c, pp, 1);
-	hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
-	end_timed(c, pp, timed_);
+	// Fused primary stage (MIS): no k_raygen launch.  k_trace generates the camera ray of path p at refill and k_shade
+	// generates it again (same function, same bits) instead of both reading what k_raygen would have written: slots are
+	// dense (slot p = path p), hits land in queue 0's hit column.
+	const bool fused = c->estimator == PT_EST_MIS && c->fused_primary;
+	if (!fused) {
+		const bool timed_ = begin_timed(c, pp, 1);
+		hipLaunchKernelGGL(k_raygen, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
+		end_timed(c, pp, timed_);
+	} else HIP_TRY(c, hipMemsetAsync(pp.ctl->shard, 0, sizeof(pp.ctl->shard), pp.stream)); // k_raygen's other job: fresh work-unit counters
 	uint32_t qi = 0;
 	if (c->estimator == PT_EST_MIS) {
 		for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
-			int rc = launch_trace(c, pp, queue_trace_args(c, pp, qi, stage > 0));
+			TraceArgs ta = queue_trace_args(c, pp, qi, stage > 0);
+			const bool primary = fused && stage == 0;
+			if (primary) {
+				ta.seg[0].ray = nullptr;
+				ta.count_ptr = nullptr; ta.n_fixed = n_total;
+				ta.cap = (((n_total + 63u) / 64u + PT_SHARDS - 1) / PT_SHARDS) * 64u; // whole 64-ray units per region, dense slots
+				memcpy(ta.cam, c->cam, sizeof ta.cam);
+				ta.width = c->cfg.width; ta.height = c->cfg.height; ta.n_paths_frame = c->n_paths;
+				ta.partition = c->cfg.partition; ta.rank = c->cfg.rank; ta.world = c->cfg.world;
+				for (uint32_t i = 0; i < n_batch; i++) ta.seeds[i] = seeds[i];
+			}
+			int rc = launch_trace(c, pp, ta, primary);
 			if (rc) return rc;
 			sa.in = pp.q[qi]; sa.out = pp.q[qi ^ 1u]; sa.in_q = qi; sa.stage = stage;
 			const bool timed_ = begin_timed(c, pp, 1);
-			hipLaunchKernelGGL(k_shade, sgrid, sblock, 0, pp.stream, sa);
+			if (primary) hipLaunchKernelGGL(k_shade<true>, dim3((n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK), sblock, 0, pp.stream, sa);
+			else hipLaunchKernelGGL(k_shade<false>, sgrid, sblock, 0, pp.stream, sa);
 			end_timed(c, pp, timed_);
 			qi ^= 1u;
 		}
@@ -813,7 +838,7 @@ int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n,
 	ta.spill = sp->spill;
 	// the spill tail is sized for PT_NOALLOC_MAX_BLOCKS blocks: k_trace is persistent, any grid drains the work counters
 	const uint32_t grid = (uint32_t) c->trace_grid < PT_NOALLOC_MAX_BLOCKS ? (uint32_t) c->trace_grid : PT_NOALLOC_MAX_BLOCKS;
-	hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+	hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
 	HIP_TRY(c, hipGetLastError());
 	return PT_OK;
 }
