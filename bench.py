@@ -309,7 +309,8 @@ def main():
     sec = avg_launch_ms * 1e-3
     workload_key = f"{args.scene}-{args.width}x{args.height}-b{args.bounces}"
     pmc = pmc_profile(workload_key)
-    pk = (pmc or {}).get("kernels", {}).get("k_trace", {})
+    kern = (pmc or {}).get("kernels", {})
+    pk = kern.get("k_trace_all") or kern.get("k_trace", {})  # all trace launches of a batch, like the HIP-event average here
     traffic = None
     if pk.get("hbm_bytes_per_launch"):
         # per ray as profiled, scaled to this run's rays per launch (batch sizes may differ between the two runs)

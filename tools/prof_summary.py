@@ -12,11 +12,19 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 
 
 def short(name):
-    name = name.split("(")[0]
-    for k in ("k_trace", "k_shade", "k_raygen", "k_pack", "k_unpack"):
-        if k in name:
-            return k + ("<count>" if "Lb1" in name or "<true>" in name else "")
-    return name[:40]
+    """k_trace<COUNT, GEN> -> k_trace / k_trace<primary> (+ <count>); k_shade<PRIMARY> -> k_shade / k_shade<primary>."""
+    base = name.split("(")[0].replace("void ", "").strip()
+    args = [a.strip() for a in base[base.index("<") + 1: base.rindex(">")].split(",")] if "<" in base and ">" in base else []
+    if "k_trace" in base:
+        return "k_trace" + ("<primary>" if len(args) > 1 and args[1] == "true" else "") + ("<count>" if args and args[0] == "true" else "")
+    if "k_shade_alt" in base:
+        return "k_shade_alt"
+    if "k_shade" in base:
+        return "k_shade" + ("<primary>" if args and args[0] == "true" else "")
+    for k in ("k_raygen", "k_resolve", "k_pack", "k_unpack"):
+        if k in base:
+            return k
+    return base[:40]
 
 
 print("== kernel-trace stats (rocprofv3 --kernel-trace --stats)")
@@ -79,7 +87,19 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
         k = short(row["Name"])
         if k in kern:
             kern[k]["avg_launch_ms_kernel_trace"] = float(row["AverageNs"]) / 1e6
-if "k_trace" in kern and plain.get("trace_launches"):
+# "k_trace_all": every trace launch of a batch (primary + bounce stages), launch-weighted -- the population bench.py's
+# HIP-event average and rays-per-launch are taken over
+tr = [k for k in kern if k.startswith("k_trace") and "count" not in k]
+if tr:
+    n = sum(kern[k]["launches_profiled"] for k in tr) or 1
+    allk = {"launches_profiled": n}
+    for f in ("fetch_size_kb", "write_size_kb", "hbm_bytes_per_launch", "l1_miss_share", "l2_hit_rate", "avg_launch_ms_kernel_trace"):
+        if all(f in kern[k] for k in tr):
+            allk[f] = sum(kern[k][f] * kern[k]["launches_profiled"] for k in tr) / n
+    if plain.get("trace_launches"):
+        allk["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
+    kern["k_trace_all"] = allk
+if False and "k_trace" in kern and plain.get("trace_launches"):
     kern["k_trace"]["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
 if kern:
     json.dump({"workload": "bunny-1920x1080-b5", "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
