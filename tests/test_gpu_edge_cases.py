@@ -184,3 +184,57 @@ def test_main_equivalent_driver_with_a_gltf_model(pt, ol, tmp_path):
     ref, _ = ol.render(ol.scene_from_desc(sc.desc()), pt.default_camera(), 128, 96, pt.frame_seeds(0, 4), bounces=5)
     assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
     assert mine[..., :3].max() > 0.1    # the emissive-strength ceiling panel lights the box
+
+
+def test_retired_dead_paths_differ_only_where_the_reference_yields_nan(pt, ol):
+    """retiring zero-throughput paths (the default) is 'same image' only while a dead path's later bounces stay
+    finite.  A zero-area emissive triangle makes pdf_light_area infinite, the balance heuristic inf/inf = NaN, and the
+    shader's color += throughput * direct turns 0 * NaN into NaN (framebuffer.comp:984-1006).  With
+    PT_FLAG_TRACE_DEAD_PATHS the kernels reproduce those NaN pixels bit for bit; without it they stay finite there and
+    equal the reference everywhere else."""
+    s = pt.Scene()
+    black = s.add_material([0, 0, 0], [0, 0, 0], [0, 0, 0])                       # Lambert, albedo 0: every path that lands here is dead
+    grey = s.add_material([0.7, 0.7, 0.7], [0, 0, 0], [0, 0, 0])
+    light = s.add_material([0, 0, 0], [0, 0, 0], [9, 9, 9], mat_type=pt.MAT_LIGHT)
+
+    def quad(a, b, c, d, mat):
+        a, b, c, d = (np.array(p, np.float32) for p in (a, b, c, d))
+        n = np.cross(b - a, c - a)
+        n = (n / np.linalg.norm(n)).astype(np.float32)
+        s.add_triangles(np.stack([np.concatenate([a, b, c]), np.concatenate([a, c, d])]), np.tile(n, (2, 3)), [mat, mat])
+    quad([-3, -1, -3], [3, -1, -3], [3, -1, -9], [-3, -1, -9], black)             # floor
+    quad([-3, -1, -9], [3, -1, -9], [3, 3, -9], [-3, 3, -9], grey)                # back wall
+    quad([-1, 2.9, -5], [-1, 2.9, -7], [1, 2.9, -7], [1, 2.9, -5], light)         # a real light, facing down
+    p = np.array([0.5, 1.0, -6.0] * 3, np.float32)                                # zero-area emissive triangle
+    s.add_triangles(p[None, :], np.tile(np.array([0, 1, 0], np.float32), (1, 3)), [light])
+    s.finalize()
+    cam, seeds = pt.default_camera(), pt.frame_seeds(0, 4)
+    ref, _ = ol.render(ol.scene_from_desc(s.desc()), cam, 96, 64, seeds, bounces=5)
+    imgs = {}
+    for flags in (pt.PT_FLAG_TRACE_DEAD_PATHS, 0):
+        c = pt.PathTracer(96, 64, flags=flags)
+        try:
+            c.upload_scene(s)
+            c.set_camera(cam)
+            c.render(0, seeds, 5)
+            imgs[flags] = c.read_framebuffer()
+        finally:
+            c.close()
+    nan_ref = np.isnan(ref[..., :3]).any(axis=2)
+    assert nan_ref.sum() > 0                                                       # the scene does provoke the case
+    assert np.array_equal(imgs[pt.PT_FLAG_TRACE_DEAD_PATHS].view(np.uint32), ref.view(np.uint32))
+    retired = imgs[0]
+    same = (retired.view(np.uint32) == ref.view(np.uint32)).all(axis=2)
+    assert same[~nan_ref].all()                                                    # identical wherever the reference is finite
+    assert (~same).sum() > 0 and np.isfinite(retired[~same]).all()                 # and finite where only a dead path made it NaN
+
+
+def test_upload_rejects_misshaped_textures(pt):
+    c = pt.PathTracer(8, 8)
+    try:
+        with pytest.raises(pt.PtError, match="tex_rgb8"):
+            c.upload_scene(pt.Scene.cornell(), tex_rgb8=np.zeros((2, 256, 256, 3), np.uint8))
+        with pytest.raises(pt.PtError, match="env_rgb8"):
+            c.upload_scene(pt.Scene.cornell(), env_rgb8=np.zeros((16, 32), np.uint8))
+    finally:
+        c.close()
