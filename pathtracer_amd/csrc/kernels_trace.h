@@ -258,6 +258,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	// One N step on the record (q0..q3) for this lane's ray: fc:352-418 minus the triangle loop (see k_trace's header).
 	auto node_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
 		if (COUNT) n_steps++;
+#ifdef PT_EXP_DUP_N
+		{ // diagnostic only: both slab tests a second time on a perturbed ray, result kept alive but never used
+			float a0, a1, a2, a3;
+			const v3 ro2 = V(ro.x + 1.0f, ro.y, ro.z);
+			box_pair_test(q0, q1, ro2, inv, tmax, &a0, &a1);
+			box_pair_test(q2, q3, ro2, inv, tmax, &a2, &a3);
+			if (a0 + a1 + a2 + a3 == 12345.678f) best_v = a0;
+		}
+#endif
 		float le, lx, re, rx;
 		box_pair_test(q0, q1, ro, inv, tmax, &le, &lx);
 		box_pair_test(q2, q3, ro, inv, tmax, &re, &rx);
@@ -427,6 +436,19 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
 				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
 				if (tmode) {
+#ifdef PT_EXP_DUP_T
+					{ // diagnostic only: the triangle arithmetic a second time on a perturbed ray, result kept alive but never used
+						const v3 rd2 = V(rd.x + 1.0f, rd.y, rd.z), ro2 = V(ro.x, ro.y + 1.0f, ro.z);
+						const v3 xv0 = V(q0.x, q0.y, q0.z), xe1 = V(q1.x, q1.y, q1.z), xe2 = V(q2.x, q2.y, q2.z);
+						const v3 xpv = cross(rd2, xe2);
+						const float xdet = dot(xe1, xpv), xinv = 1.0f / xdet;
+						const v3 xtv = ro2 - xv0;
+						const float xu = dot(xtv, xpv) * xinv;
+						const v3 xqv = cross(xtv, xe1);
+						const float xv = xinv * dot(rd2, xqv), xt = xinv * dot(xe2, xqv);
+						if (xu + xv + xt == 12345.678f) best_u = xt;
+					}
+#endif
 					// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
 					if (COUNT) n_tests++;
 					tri += 64u;
