@@ -373,6 +373,19 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 		c->stride = c->cap * PT_SHARDS;
 	}
 	const size_t qbytes = (size_t) kQueueCols * c->stride * 4;
+	{
+		// say what is needed before the first hipMalloc fails half way: per pipeline two queues, the sample store and the
+		// spill tail; the image once
+		const size_t per_pipe = 2 * qbytes + ((size_t) c->max_batch * c->n_paths + 1) * 16 + (size_t) c->trace_grid * PT_TRACE_WAVES * PT_SPILL_STACK * 64 * 4 + sizeof(DevCtl);
+		const size_t need = per_pipe * c->n_pipes + (size_t) cfg->width * cfg->height * 16;
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
+			fail(nullptr, PT_ENOMEM, "pt_create: %ux%u with %u frames per launch set and %u pipeline(s) needs %.2f GB of device memory, %.2f GB are free; lower pt_config.max_batch",
+			     cfg->width, cfg->height, c->max_batch, c->n_pipes, need / 1e9, free_b / 1e9);
+			pt_destroy(c);
+			return PT_ENOMEM;
+		}
+	}
 	for (uint32_t i = 0; i < c->n_pipes; i++) {
 		Pipe &pp = c->pipe[i];
 		CREATE_TRY(hipMalloc(&pp.queue_alloc, 2 * qbytes));

@@ -117,3 +117,13 @@ def test_non_contiguous_sibling_leaves(pt, ol):
     assert (kind == 1).mean() > 0.2
     assert np.array_equal(kind, okind) and np.array_equal(prim, oprim) and np.array_equal(th, oth)
     assert np.array_equal(uv.view(np.uint32), ouv.view(np.uint32))
+
+
+def test_create_says_how_much_memory_it_needs(pt):
+    """An image whose queues cannot fit (16384 x 16384 = the largest size pt_create accepts, 4 pipelines) is refused with the
+    figures, before any allocation fails half way; the same image with a one-frame batch and one pipeline is accepted
+    or refused by the same rule, never by a raw hipMalloc error."""
+    with pytest.raises(pt.PtError, match="needs .* GB of device memory"):
+        pt.PathTracer(16384, 16384, max_batch=32, pipelines=4)
+    c = pt.PathTracer(2048, 2048, max_batch=1)
+    c.close()
