@@ -111,6 +111,11 @@ int pth_scene_add_model(pth_scene *s, const pth_model *m);
 int pth_decode_png_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels);
 int pth_resize_rgb8_512(const uint8_t *rgb, int w, int h, uint8_t *out512);
 
+/* The environment map as Display::InitRenderBuffer loads it (src/display/display.cpp:183-189): a Radiance .hdr through
+ * stbi_load with stbi_hdr_to_ldr_gamma(1.0), 3 channels -> 8 bits per channel, rows in file order = what goes to
+ * pt_scene_desc.env_rgb8 / env_w / env_h.  out == NULL: only report the size.  Own RGBE reader. */
+int pth_load_env_hdr(const char *path, uint8_t *out, size_t capacity, uint32_t *w, uint32_t *h);
+
 /* Procedural stand-ins (no assets exist offline: the reference git-ignores .glb / .hdr files).
  * Cornell box: 5 walls + ceiling light quad + two boxes = 36 triangles, placed like src/main.cpp:26-28.
  * flags bit0: add the four gold GGX spheres of src/main.cpp:44-51. */

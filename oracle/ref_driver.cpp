@@ -253,6 +253,19 @@ int ref_stbi_load_rgb8(const uint8_t *file, size_t n, uint8_t *out, size_t capac
 	stbi_image_free(img);
 	return bytes <= capacity ? 0 : 2;
 }
+// The env map exactly as Display::InitRenderBuffer gets it (src/display/display.cpp:183-184, minus the file name):
+// stbi_hdr_to_ldr_gamma(1.0), then stbi_load with 3 channels.
+int ref_env_hdr_load(const char *path, uint8_t *out, size_t capacity, int *w, int *h)
+{
+	int c = -1;
+	stbi_hdr_to_ldr_gamma(1.0);
+	uint8_t *data = stbi_load(path, w, h, &c, 3);
+	if (!data) return 1;
+	const size_t bytes = (size_t) *w * *h * 3;
+	if (bytes <= capacity) memcpy(out, data, bytes);
+	stbi_image_free(data);
+	return bytes <= capacity ? 0 : 2;
+}
 int ref_stbir_resize_512(const uint8_t *rgb, int w, int h, uint8_t *out512) { return stbir_resize_uint8(rgb, w, h, 0, out512, 512, 512, 0, 3); }
 
 } // extern "C"

@@ -139,6 +139,7 @@ EXPORTS = {
     "pth_model_get": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pth_model_textures": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint32), c_void_p]),
     "pth_scene_add_model": (c_int, [c_void_p, c_void_p]),
+    "pth_load_env_hdr": (c_int, [c_char_p, c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32)]),
     "pth_decode_png_rgb8": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "pth_resize_rgb8_512": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
@@ -580,6 +581,17 @@ class Group:
         c = pt_counters()
         self._check(lib().pt_group_get_counters(self._h, byref(c)), "pt_group_get_counters")
         return c.as_dict()
+
+
+def load_env_hdr(path: str) -> np.ndarray:
+    """Radiance .hdr -> the 8-bit RGB image Display::InitRenderBuffer uploads as the env map (u8 [h, w, 3])."""
+    w, h = c_uint32(), c_uint32()
+    if lib().pth_load_env_hdr(os.fsencode(path), None, 0, byref(w), byref(h)) != 0:
+        raise PtError(lib().pth_last_error().decode())
+    out = np.zeros((h.value, w.value, 3), np.uint8)
+    if lib().pth_load_env_hdr(os.fsencode(path), _ptr(out), out.size, None, None) != 0:
+        raise PtError(lib().pth_last_error().decode())
+    return out
 
 
 def make_textures(layers: int = 6, seed: int = 1) -> np.ndarray:

@@ -799,6 +799,90 @@ int pth_scene_add_model(pth_scene *s, const pth_model *m)
 	return pth_scene_add_triangles(s, &m->v[0].x, &m->n[0].x, m->uv.data(), mat.data(), (uint32_t) mat.size());
 }
 
+// The environment map as Display::InitRenderBuffer loads it (src/display/display.cpp:183-189): a Radiance .hdr read by
+// stbi_load with stbi_hdr_to_ldr_gamma(1.0) and 3 channels, i.e. converted to 8 bits per channel as
+// (uint8) clamp(v * 255 + 0.5, 0, 255) with v = mantissa * 2^(e - 136) in float -- and handed to glTextureSubImage2D as
+// GL_UNSIGNED_BYTE.  Own RGBE reader (header, "-Y h +X w", flat or run-length scanlines); rows in file order.
+// Two-call pattern: out == NULL reports the size.
+int pth_load_env_hdr(const char *path, uint8_t *out, size_t capacity, uint32_t *w_out, uint32_t *h_out)
+{
+	if (!path) return fail("pth_load_env_hdr: null path");
+	std::vector<uint8_t> f;
+	if (!read_file(path, f)) return fail("pth_load_env_hdr: cannot read %s", path);
+	size_t o = 0;
+	auto line = [&]() { // one header line without its newline
+		std::string l;
+		while (o < f.size() && f[o] != '\n') l += (char) f[o++];
+		if (o < f.size()) o++;
+		return l;
+	};
+	const std::string magic = line();
+	if (magic != "#?RADIANCE" && magic != "#?RGBE") return fail("pth_load_env_hdr: %s is not a Radiance HDR file", path);
+	bool valid = false;
+	for (;;) {
+		const std::string l = line();
+		if (l.empty()) break;
+		if (l == "FORMAT=32-bit_rle_rgbe") valid = true;
+		if (o >= f.size()) break;
+	}
+	if (!valid) return fail("pth_load_env_hdr: unsupported HDR format (FORMAT=32-bit_rle_rgbe expected)");
+	const std::string dims = line();
+	int height = 0, width = 0;
+	if (sscanf(dims.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0 || width > (1 << 24) || height > (1 << 24))
+		return fail("pth_load_env_hdr: unsupported data layout '%s' (-Y h +X w expected)", dims.c_str());
+	if (w_out) *w_out = (uint32_t) width;
+	if (h_out) *h_out = (uint32_t) height;
+	const size_t need = (size_t) width * height * 3;
+	if (!out) return PT_OK;
+	if (capacity < need) return fail("pth_load_env_hdr: output needs %zu bytes", need);
+	auto convert = [&](const uint8_t *rgbe, uint8_t *dst) {
+		float v[3] = {0.0f, 0.0f, 0.0f};
+		if (rgbe[3] != 0) {
+			const float f1 = (float) ldexp(1.0f, (int) rgbe[3] - (128 + 8));
+			for (int k = 0; k < 3; k++) v[k] = (float) rgbe[k] * f1;
+		}
+		for (int k = 0; k < 3; k++) {
+			float z = (float) pow((double) (v[k] * 1.0f), (double) 1.0f) * 255 + 0.5f; // scale 1, gamma 1 (display.cpp:183)
+			if (z < 0) z = 0;
+			if (z > 255) z = 255;
+			dst[k] = (uint8_t) (int) z;
+		}
+	};
+	std::vector<uint8_t> scan((size_t) width * 4);
+	bool flat = width < 8 || width >= 32768;
+	for (int j = 0; j < height; j++) {
+		if (!flat) {
+			if (o + 4 > f.size()) return fail("pth_load_env_hdr: truncated file");
+			if (f[o] != 2 || f[o + 1] != 2 || (f[o + 2] & 0x80)) flat = true; // not run-length encoded: this and everything after it is flat RGBE
+			else {
+				if ((((int) f[o + 2]) << 8 | f[o + 3]) != width) return fail("pth_load_env_hdr: invalid decoded scanline length (corrupt HDR)");
+				o += 4;
+				for (int k = 0; k < 4; k++) {
+					int i = 0;
+					while (i < width) {
+						if (o >= f.size()) return fail("pth_load_env_hdr: truncated file");
+						int count = f[o++];
+						if (count > 128) {
+							count -= 128;
+							if (o >= f.size() || count == 0 || count > width - i) return fail("pth_load_env_hdr: corrupt run (bad RLE data in HDR)");
+							const uint8_t value = f[o++];
+							for (int z = 0; z < count; z++) scan[(size_t) (i++) * 4 + k] = value;
+						} else {
+							if (count == 0 || count > width - i || o + (size_t) count > f.size()) return fail("pth_load_env_hdr: corrupt dump (bad RLE data in HDR)");
+							for (int z = 0; z < count; z++) scan[(size_t) (i++) * 4 + k] = f[o++];
+						}
+					}
+				}
+				for (int i = 0; i < width; i++) convert(&scan[(size_t) i * 4], out + ((size_t) j * width + i) * 3);
+				continue;
+			}
+		}
+		if (o + (size_t) width * 4 > f.size()) return fail("pth_load_env_hdr: truncated file");
+		for (int i = 0; i < width; i++, o += 4) convert(&f[o], out + ((size_t) j * width + i) * 3);
+	}
+	return PT_OK;
+}
+
 // Test hooks for the two image steps of the textured path (stbi_load_from_memory with 3 channels, stbir_resize_uint8 to
 // 512 x 512: loader.cpp:209-232), so that each can be checked against the reference's own stb build.
 int pth_decode_png_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels)

@@ -286,3 +286,64 @@ def test_textured_glb_fills_the_layer_array(pt, tmp_path):
     assert mats[0, 11] == 0.0 and mats[1, 11] == 1.0                       # diffuse_tex_index = load order
     sc = pt.Scene.from_gltf(str(f), spheres=False)
     assert sc.textures.shape[0] == 3 and sc.tex_sampler == (33071, 33648, 9728)
+
+
+# ------------------------------------------------------------------ environment map (.hdr)
+def _write_hdr(path, rgbe, rle):
+    """Own minimal Radiance writer: rgbe u8 [h, w, 4]; rle = new-style run-length scanlines (w in 8..32767)."""
+    h, w = rgbe.shape[:2]
+    out = bytearray(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode())
+    for y in range(h):
+        if not rle:
+            out += rgbe[y].tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            ch = rgbe[y, :, k]
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and ch[i + run] == ch[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, int(ch[i])])
+                    i += run
+                else:
+                    j = i
+                    while j < w and j - i < 128 and not (j + 2 < w and ch[j] == ch[j + 1] == ch[j + 2]):
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + ch[i:j].tobytes()
+                    i = j
+    with open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_env_hdr_loader(pt, ol, tmp_path, rle):
+    rng = np.random.default_rng(12)
+    h, w = 20, 48
+    rgbe = np.zeros((h, w, 4), np.uint8)
+    rgbe[..., :3] = rng.integers(0, 256, (h, w, 3))
+    rgbe[..., 3] = rng.integers(118, 134, (h, w))       # exponents around 128: values from ~0.001 to ~32
+    rgbe[2, 5:30] = [200, 100, 50, 129]                 # a run, so the RLE writer emits run packets
+    rgbe[3, :, 3] = 0                                   # exponent 0 = black
+    path = str(tmp_path / "env.hdr")
+    _write_hdr(path, rgbe, rle)
+    img = pt.load_env_hdr(path)
+    assert img.shape == (h, w, 3)
+    # closed form: v = m * 2^(e - 136); 8-bit = clamp(v * 255 + 0.5)
+    v = rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:4].astype(np.float32) - 136.0).astype(np.float32)
+    v[rgbe[..., 3] == 0] = 0
+    want = np.clip(v * np.float32(255) + np.float32(0.5), 0, 255).astype(np.uint8)
+    assert np.array_equal(img, want)
+    R = ol.load_ref()
+    if R is not None and hasattr(R, "ref_env_hdr_load"):   # the reference's own stb call sequence (build container)
+        ref = np.zeros((h, w, 3), np.uint8)
+        ww, hh = ctypes.c_int(), ctypes.c_int()
+        assert R.ref_env_hdr_load(path.encode(), ctypes.c_void_p(ref.ctypes.data), ctypes.c_size_t(ref.size), ctypes.byref(ww), ctypes.byref(hh)) == 0
+        assert (ww.value, hh.value) == (w, h) and np.array_equal(img, ref)
+    with pytest.raises(pt.PtError, match="not a Radiance"):
+        bad = tmp_path / "bad.hdr"
+        bad.write_bytes(b"P6\n1 1\n255\n\0\0\0")
+        pt.load_env_hdr(str(bad))
