@@ -107,8 +107,10 @@ int pth_model_textures(const pth_model *m, const uint8_t **rgb8, uint32_t *layer
  * src/main.cpp:44-51, then pth_scene_finalize) */
 int pth_scene_add_model(pth_scene *s, const pth_model *m);
 /* the two image steps of the textured path on their own (stbi_load_from_memory with 3 channels; stbir_resize_uint8 to
- * 512 x 512: src/loader.cpp:209-232), exposed so tests can check each against the reference's stb build */
-int pth_decode_png_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels);
+ * 512 x 512: src/loader.cpp:209-232), exposed so tests can check each against the reference's stb build.  The decoder
+ * takes PNG (8/16-bit, non-interlaced) and JPEG (8-bit baseline / extended / progressive, 1 or 3 components), chosen by
+ * signature; its bytes equal stb_image's for both */
+int pth_decode_image_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels);
 int pth_resize_rgb8_512(const uint8_t *rgb, int w, int h, uint8_t *out512);
 
 /* The environment map as Display::InitRenderBuffer loads it (src/display/display.cpp:183-189): a Radiance .hdr through

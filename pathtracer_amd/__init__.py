@@ -140,7 +140,7 @@ EXPORTS = {
     "pth_model_textures": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_uint32), c_void_p]),
     "pth_scene_add_model": (c_int, [c_void_p, c_void_p]),
     "pth_load_env_hdr": (c_int, [c_char_p, c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32)]),
-    "pth_decode_png_rgb8": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "pth_decode_image_rgb8": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "pth_resize_rgb8_512": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "pth_tonemap_rgb8": (c_int, [c_void_p, c_uint32, c_uint32, c_void_p]),
     "pth_write_ppm": (c_int, [c_char_p, c_void_p, c_uint32, c_uint32]),

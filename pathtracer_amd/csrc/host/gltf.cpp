@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "../../../include/pt355_host.h"
+#include "image_decode.h"
 #include "layouts.h"
 
 namespace {
@@ -413,7 +414,7 @@ uint32_t be32(const uint8_t *p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p
 int decode_png_rgb8(const uint8_t *d, size_t n, std::vector<uint8_t> &rgb, int *w, int *h, int *channels)
 {
 	static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-	if (n < 8 || memcmp(d, sig, 8) != 0) return fail("LoadGLTF: texture is not a PNG (JPEG and other formats are not supported by this build)");
+	if (n < 8 || memcmp(d, sig, 8) != 0) return fail("LoadGLTF: texture is neither a PNG nor a JPEG (other formats are not supported by this build)");
 	size_t o = 8;
 	uint32_t W = 0, H = 0;
 	int depth = 0, ctype = 0, interlace = 0;
@@ -466,6 +467,17 @@ int decode_png_rgb8(const uint8_t *d, size_t n, std::vector<uint8_t> &rgb, int *
 	*w = (int) W; *h = (int) H;
 	*channels = ctype == 3 ? 3 : nch; // stbi reports the file's channel count (palette images count as RGB)
 	return PT_OK;
+}
+
+// A texture's bytes -> RGB8: PNG or JPEG by signature (stbi_load_from_memory tries JPEG first, then PNG: stb_image.h:1127-1140)
+int decode_image_rgb8(const uint8_t *d, size_t n, std::vector<uint8_t> &rgb, int *w, int *h, int *channels)
+{
+	if (n >= 3 && d[0] == 0xff && d[1] == 0xd8) {
+		std::string err;
+		if (pth_internal_decode_jpeg_rgb8(d, n, rgb, w, h, channels, err)) return fail("LoadGLTF: JPEG texture: %s", err.c_str());
+		return PT_OK;
+	}
+	return decode_png_rgb8(d, n, rgb, w, h, channels);
 }
 
 // Separable resample to 512 x 512 with the filters stbir_resize_uint8 picks by default (stb_image_resize.h: Catmull-Rom when
@@ -604,7 +616,7 @@ int load_material(const Doc &d, const JVal *jm, pth_model *out, int *num_loaded_
 				const View &view = d.views[iv];
 				std::vector<uint8_t> rgb;
 				int w = 0, h = 0, channels = 0;
-				if (int rc = decode_png_rgb8(d.buffers[view.buffer].data.data() + view.offset, view.size, rgb, &w, &h, &channels)) return rc;
+				if (int rc = decode_image_rgb8(d.buffers[view.buffer].data.data() + view.offset, view.size, rgb, &w, &h, &channels)) return rc;
 				const int layer = (*num_loaded_textures)++;
 				tex_index = layer;
 				if ((uint32_t) layer >= num_textures) return fail("LoadGLTF: more textured primitives (%d) than textures (%u): the reference's array has one layer per glTF texture (loader.cpp:52-57)", layer + 1, num_textures);
@@ -885,16 +897,16 @@ int pth_load_env_hdr(const char *path, uint8_t *out, size_t capacity, uint32_t *
 
 // Test hooks for the two image steps of the textured path (stbi_load_from_memory with 3 channels, stbir_resize_uint8 to
 // 512 x 512: loader.cpp:209-232), so that each can be checked against the reference's own stb build.
-int pth_decode_png_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels)
+int pth_decode_image_rgb8(const uint8_t *png, size_t n, uint8_t *rgb_out, size_t rgb_capacity, int *w, int *h, int *channels)
 {
 	std::vector<uint8_t> rgb;
 	int ww = 0, hh = 0, ch = 0;
-	if (int rc = decode_png_rgb8(png, n, rgb, &ww, &hh, &ch)) return rc;
+	if (int rc = decode_image_rgb8(png, n, rgb, &ww, &hh, &ch)) return rc;
 	if (w) *w = ww;
 	if (h) *h = hh;
 	if (channels) *channels = ch;
 	if (rgb_out) {
-		if (rgb.size() > rgb_capacity) return fail("pth_decode_png_rgb8: output needs %zu bytes", rgb.size());
+		if (rgb.size() > rgb_capacity) return fail("pth_decode_image_rgb8: output needs %zu bytes", rgb.size());
 		memcpy(rgb_out, rgb.data(), rgb.size());
 	}
 	return PT_OK;

@@ -190,9 +190,9 @@ def _png(rgb, color_type=2, filt=None):
 def _decode(pt, png):
     buf = np.frombuffer(png, np.uint8)
     w, h, ch = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    assert pt.lib().pth_decode_png_rgb8(buf.ctypes.data, buf.size, None, 0, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)) == 0
+    assert pt.lib().pth_decode_image_rgb8(buf.ctypes.data, buf.size, None, 0, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ch)) == 0
     out = np.zeros((h.value, w.value, 3), np.uint8)
-    assert pt.lib().pth_decode_png_rgb8(buf.ctypes.data, buf.size, out.ctypes.data, out.size, None, None, None) == 0
+    assert pt.lib().pth_decode_image_rgb8(buf.ctypes.data, buf.size, out.ctypes.data, out.size, None, None, None) == 0
     return out, ch.value
 
 
@@ -218,6 +218,61 @@ def test_png_decoder(pt, ol):
             assert R.ref_stbi_load_rgb8(ctypes.c_void_p(png.ctypes.data), ctypes.c_size_t(png.size), ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.size), ctypes.byref(ww), ctypes.byref(hh), ctypes.byref(cc)) == 0
             mine, ch = _decode(pt, png.tobytes())
             assert (ww.value, hh.value, cc.value) == (w, h, ch) and np.array_equal(mine, out)
+
+
+JPEG = os.path.join(ROOT, "tests", "golden", "jpeg")
+JPEG_CASES = sorted(f[:-4] for f in os.listdir(JPEG) if f.endswith(".jpg"))
+
+
+@pytest.mark.parametrize("name", JPEG_CASES)
+def test_jpeg_decoder_equals_the_reference_s_stb(pt, ol, golden, name):
+    """tests/golden/jpeg/*.jpg (baseline / progressive / 4:4:4, 4:2:2, 4:2:0, 4:1:1, 4:4:0, mixed and 4x2 sampling /
+    greyscale / restart intervals / optimised tables / 'RGB' ids / Adobe markers / 16-bit tables whose products wrap /
+    1-pixel-wide edge cases): every byte equals what the reference's own stb_image build returned for the file
+    (tests/golden/ref_jpeg.npz, made by tests/golden/make_golden_jpeg.py), and again live where that build exists."""
+    G = golden("ref_jpeg.npz")
+    data = open(os.path.join(JPEG, name + ".jpg"), "rb").read()
+    got, ch = _decode(pt, data)
+    assert ch == int(G[name + "_channels"]) and got.shape == G[name].shape and np.array_equal(got, G[name])
+    R = ol.load_ref()
+    if R is not None and hasattr(R, "ref_stbi_load_rgb8"):
+        buf = np.frombuffer(data, np.uint8)
+        out = np.zeros_like(got)
+        ww, hh, cc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert R.ref_stbi_load_rgb8(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.size), ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.size), ctypes.byref(ww), ctypes.byref(hh), ctypes.byref(cc)) == 0
+        assert np.array_equal(out, got) and cc.value == ch
+
+
+def test_jpeg_decoder_on_fresh_files(pt, ol):
+    """files written on the spot by tests/jpeg_writer.py: the decoded picture is the encoded one to within the
+    quantisation (so the fixtures are pictures, not noise that two decoders happen to agree on), equals stb's where the
+    reference build exists, and damaged / unsupported files are refused with a message"""
+    import jpeg_writer as jw
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:40, 0:52]
+    img = np.stack([xx * 4, yy * 6, 255 - xx * 2 - yy * 2], 2).clip(0, 255).astype(np.uint8)
+    R = ol.load_ref()
+    for sampling in ([(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(2, 2), (2, 1), (1, 2)]):
+        hmax, vmax = max(s[0] for s in sampling), max(s[1] for s in sampling)
+        planes = [jw.subsample(c, hmax // s[0], vmax // s[1]) for c, s in zip(jw.rgb_to_ycc(img), sampling)]
+        data = jw.encode(planes, sampling, 52, 40, quant=[2] * 64, restart=int(rng.integers(0, 4)))
+        got, ch = _decode(pt, data)
+        assert ch == 3 and np.abs(got.astype(int) - img.astype(int)).mean() < 3.0, sampling
+        if R is not None and hasattr(R, "ref_stbi_load_rgb8"):
+            buf = np.frombuffer(data, np.uint8)
+            out = np.zeros_like(got)
+            ww, hh, cc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            assert R.ref_stbi_load_rgb8(ctypes.c_void_p(buf.ctypes.data), ctypes.c_size_t(buf.size), ctypes.c_void_p(out.ctypes.data), ctypes.c_size_t(out.size), ctypes.byref(ww), ctypes.byref(hh), ctypes.byref(cc)) == 0
+            assert np.array_equal(out, got)
+    good = jw.encode([img[..., 1]], [(1, 1)], 52, 40)
+    got, ch = _decode(pt, good)
+    assert ch == 1 and (got[..., 0] == got[..., 2]).all() and np.abs(got[..., 0].astype(int) - img[..., 1]).mean() < 4.0
+    w = ctypes.c_int()
+    cmyk = jw.encode([img[..., 0], img[..., 1], img[..., 2], img[..., 0]], [(1, 1)] * 4, 52, 40, ids=(1, 2, 3, 4))
+    for bad, what in ((cmyk, "CMYK"), (good[:200].replace(b"\xff\xc0", b"\xff\xc9"), "arithmetic"), (b"\xff\xd8\xff\xd9", "SOF"), (b"GIF89a" + bytes(20), "neither")):
+        buf = np.frombuffer(bad, np.uint8)
+        assert pt.lib().pth_decode_image_rgb8(buf.ctypes.data, buf.size, None, 0, ctypes.byref(w), ctypes.byref(w), ctypes.byref(w)) != 0
+        assert what in pt.lib().pth_last_error().decode(), (what, pt.lib().pth_last_error())
 
 
 def _resize(pt, img):
@@ -286,6 +341,31 @@ def test_textured_glb_fills_the_layer_array(pt, tmp_path):
     assert mats[0, 11] == 0.0 and mats[1, 11] == 1.0                       # diffuse_tex_index = load order
     sc = pt.Scene.from_gltf(str(f), spheres=False)
     assert sc.textures.shape[0] == 3 and sc.tex_sampler == (33071, 33648, 9728)
+
+
+def test_textured_glb_with_a_jpeg_image(pt, tmp_path):
+    """image/jpeg buffer views go through the same path (stbi_load_from_memory sniffs the format, loader.cpp:209)"""
+    import gltf_writer as gw
+    import jpeg_writer as jw
+    yy, xx = np.mgrid[0:512, 0:512]
+    img = np.stack([xx // 2, yy // 2, (xx + yy) // 4], 2).astype(np.uint8)
+    sampling = [(2, 2), (1, 1), (1, 1)]
+    planes = [jw.subsample(c, 2 // s[0], 2 // s[1]) for c, s in zip(jw.rgb_to_ycc(img), sampling)]
+    data = jw.encode(planes, sampling, 512, 512, quant=[4] * 64)
+    g = gw.Glb()
+    g.j["images"] = [{"bufferView": g.view(data), "mimeType": "image/jpeg"}]
+    g.j["textures"] = [{"source": 0}]
+    p, n, uv, i = gw.box((0, 0, 0), (0.5, 0.5, 0.5))
+    m = g.material(base=(1, 1, 1, 1), metallic=0.0, roughness=0.0)
+    g.j["materials"][m]["pbrMetallicRoughness"]["baseColorTexture"] = {"index": 0}
+    g.node(mesh=g.mesh([g.primitive(p, n, i, uv, m)]))
+    f = tmp_path / "jpg.glb"
+    f.write_bytes(g.tobytes())
+    tex, smp = pt.Model(str(f)).textures()
+    dec, ch = _decode(pt, data)
+    assert ch == 3 and tex.shape == (1, 512, 512, 3) and np.array_equal(tex[0], dec)
+    assert np.abs(dec.astype(int) - img.astype(int)).mean() < 2.0
+    assert smp == (10497, 10497, 9729)
 
 
 # ------------------------------------------------------------------ environment map (.hdr)
