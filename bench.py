@@ -36,6 +36,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+# k_trace's cache-miss read requests per record fetch on the bunny workload (profiles/r02c_pmc_traffic.json, k_trace_all);
+# used for the gather ceiling only when the workload being benched has no PMC passes of its own
+DEFAULT_MISS_L1, DEFAULT_MISS_L2 = 0.26, 0.04
 
 
 def make_scene(pt, name):
@@ -76,19 +79,20 @@ def pmc_profile(workload_key):
     return best
 
 
-def gather_ceiling(device, footprint_bytes, hot_share, active_lanes, waves_per_simd):
+def gather_ceiling(device, miss_l1, miss_l2, active_lanes, waves_per_simd):
     """Live measurement on this GPU (pathtracer_amd/libptubench.so = tools/ubench_gather.hip): lane-steps/s of dependent
-    64-byte record gathers with the trace kernel's footprint, L1-hit share, lane occupancy and resident waves, and no
-    arithmetic in between.  Returns (lane_steps_per_s, ns_per_wavestep) or None when the library is not built."""
+    64-byte record gathers at the trace kernel's cache-miss rates per record fetch (TCP->TCC and TCC->fabric read requests
+    per lane-step, from the PMC passes), its lane occupancy and resident waves, and no arithmetic in between.
+    Returns (lane_steps_per_s, ns_per_wavestep) or None when the library is not built."""
     path = os.path.join(ROOT, "pathtracer_amd", "libptubench.so")
     if not os.path.exists(path):
         return None
     L = ctypes.CDLL(path)
     L.ptu_gather_ceiling.restype = ctypes.c_int
-    L.ptu_gather_ceiling.argtypes = [ctypes.c_int, ctypes.c_ulonglong, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    L.ptu_gather_ceiling.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     ns, rate = ctypes.c_double(), ctypes.c_double()
-    rc = L.ptu_gather_ceiling(device, int(footprint_bytes), float(hot_share), int(active_lanes), int(waves_per_simd), 2000,
+    rc = L.ptu_gather_ceiling(device, float(miss_l1), float(miss_l2), int(active_lanes), int(waves_per_simd), 2000,
                               ctypes.byref(ns), ctypes.byref(rate))
     return (rate.value, ns.value) if rc == 0 else None
 
@@ -299,10 +303,12 @@ def main():
     cctx.render(0, timed[: min(cctx.max_batch, K)], args.bounces)
     cc = cctx.counters()
     trace_grid = int(cctx.info[5])
+    cctx_info = [int(v) for v in cctx.info]
     cctx.close()
     crays = cc["rays_primary"] + cc["rays_shadow"] + cc["rays_bounce"]
     S, T = cc["node_steps"] / crays, cc["tri_tests"] / crays
     lane_occ = (cc["node_steps"] + cc["tri_tests"]) / max(64.0 * cc["wave_iters"], 1.0)  # share of lanes working per traversal iteration
+    top_share = cc.get("top_steps", 0) / max(cc["node_steps"] + cc["tri_tests"], 1)   # lane-steps served by the LDS copy of the tree top
     launches = max(cnt["trace_launches"], 1)
     avg_launch_ms = cnt["ms_trace"] / launches  # HIP events recorded around every k_trace launch on the context's stream
     rays_per_launch = rays / launches
@@ -315,29 +321,57 @@ def main():
     if pk.get("hbm_bytes_per_launch"):
         # per ray as profiled, scaled to this run's rays per launch (batch sizes may differ between the two runs)
         traffic = round(pk["hbm_bytes_per_launch"] / max(pk.get("rays_per_launch", 0.0), 1.0) * rays_per_launch)
-    # (1) what binds the kernel: the vector-memory path's rate of dependent 64-byte record gathers.  One lane-step = one
-    # lane fetching one 64-B record of the traversal blob (a node pair or a triangle): rays * (S + T) of them per launch.
+    # (1) the two resources the kernel leans on, each against its own peak; `roofline` reports the busier one.
+    #  * VALU issue: wave64 vector instructions per second (SQ_INSTS_VALU of the committed PMC passes of this workload,
+    #    scaled per ray to this run) against 1 instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cyc, SIMD-32);
+    #  * vector-memory gathers: lane-steps that fetch their 64-B record from global memory (the others read the LDS copy of
+    #    the tree top) per second, against the live micro-benchmark at the kernel's own cache-miss rates and lane count.
     d = scene.desc()
     props = torch.cuda.get_device_properties(local_rank)
-    waves_per_simd = max(1, min(8, round(trace_grid / max(props.multi_processor_count, 1))))
-    blob_bytes = 64 * ((d.n_nodes - 1) // 2 + d.n_tris)
-    l1_hit = 1.0 - pk["l1_miss_share"] if "l1_miss_share" in pk else 0.915  # profiles/r01g_rocprof_summary.txt when the newer passes lack it
+    n_cu = props.multi_processor_count
+    trace_block = int(cctx_info[6]) or 256
+    waves_per_simd = max(1, min(8, round(trace_grid * (trace_block // 64) / max(4 * n_cu, 1))))
+    have_pmc = "record_miss_l1_per_lane_step" in pk
+    miss_l1 = pk.get("record_miss_l1_per_lane_step", DEFAULT_MISS_L1)
+    miss_l2 = pk.get("record_miss_l2_per_lane_step", DEFAULT_MISS_L2)
     lane_steps = (S + T) * rays_per_launch
-    achieved_ls = lane_steps / sec / 1e9 if sec > 0 else 0.0
-    ceil = gather_ceiling(local_rank, blob_bytes, l1_hit, max(1, round(lane_occ * 64)), waves_per_simd)
+    global_steps = lane_steps * (1.0 - top_share)
+    achieved_ls = global_steps / sec / 1e9 if sec > 0 else 0.0
+    gather_lanes = max(1, round(lane_occ * 64 * (1.0 - top_share)))
+    ceil = gather_ceiling(local_rank, miss_l1, miss_l2, gather_lanes, waves_per_simd)
+    pmc_name = ("PMC " + pmc["source"].split(":")[0]) if pmc else None
+    vmem = {"bound": "vmem-gather", "achieved": round(achieved_ls, 2), "peak": round(ceil[0] / 1e9, 2) if ceil else None, "unit": "G lane-steps/s",
+            "frac": round(achieved_ls / (ceil[0] / 1e9), 4) if ceil else None,
+            "peak_source": ("measured live by pathtracer_amd/libptubench.so (tools/ubench_gather.hip: ptu_gather_ceiling): dependent 64-B "
+                            f"record gathers, 4 x dwordx4 per lane-step, at the kernel's cache-miss requests per record fetch -- {miss_l1:.3f} "
+                            f"TCP->TCC and {miss_l2:.3f} TCC->fabric read requests per global lane-step ("
+                            f"{pmc_name if have_pmc else 'no PMC passes for this workload: the bunny workload figures'}), "
+                            f"{gather_lanes} of 64 lanes gathering per wave-step (counted replay), {waves_per_simd} waves/SIMD, no arithmetic"
+                            if ceil else "libptubench.so not built"),
+            "record_miss_l1_per_lane_step": round(miss_l1, 4), "record_miss_l2_per_lane_step": round(miss_l2, 4),
+            "peak_ns_per_wavestep": round(ceil[1], 2) if ceil else None,
+            "lane_steps_from_lds_share": round(top_share, 4)}
+    clock_hz = float(getattr(props, "clock_rate", 2400000)) * 1e3
+    valu_peak = 4.0 * n_cu * clock_hz / 2.0 / 1e9  # G wave-instructions/s
+    valu = None
+    if pk.get("sq_insts_valu") and pk.get("rays_per_launch"):
+        insts = pk["sq_insts_valu"] / pk["rays_per_launch"] * rays_per_launch  # same code, same scene: instructions scale with the rays
+        ach = insts / sec / 1e9 if sec > 0 else 0.0
+        valu = {"bound": "valu-issue", "achieved": round(ach, 2), "peak": round(valu_peak, 2), "unit": "G wave-instr/s", "frac": round(ach / valu_peak, 4),
+                "peak_source": f"4 SIMDs x {n_cu} CUs x {clock_hz / 1e9:.2f} GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md, SIMD-32); "
+                               f"instruction count: SQ_INSTS_VALU per ray of {pmc_name}",
+                "valu_insts_per_launch": round(insts),
+                "valu_lane_utilisation": round(pk["sq_thread_cycles_valu"] / (64.0 * pk["sq_active_inst_valu"]), 4) if pk.get("sq_active_inst_valu") else None}
     # (2) SURVEY.md 8(d)'s figure, kept for the record: algorithmic bytes against the HBM peak.  The 7 MB blob is
     # cache-served, so this "fraction" exceeds 1 and is NOT the binding roof; hbm_counter_frac is the HBM-side truth.
     bytes_per_ray = 64.0 * S + 64.0 * T + 96.0
     alg = bytes_per_ray * rays_per_launch / sec / 1e9 if sec > 0 else 0.0
-    roofline = {"bound": "vmem-gather", "kernel": "k_trace",
-                "achieved": round(achieved_ls, 2), "peak": round(ceil[0] / 1e9, 2) if ceil else None, "unit": "G lane-steps/s",
-                "frac": round(achieved_ls / (ceil[0] / 1e9), 4) if ceil else None,
-                "peak_source": ("measured live by pathtracer_amd/libptubench.so (tools/ubench_gather.hip: ptu_gather_ceiling): dependent 64-B "
-                                f"record gathers, 4 x dwordx4 per lane-step, table {blob_bytes} B = the traversal blob, {l1_hit:.3f} of the steps in a "
-                                f"16 KB hot set (the kernel's L1 hit share, {'PMC ' + pmc['source'].split(':')[0] if pmc and 'l1_miss_share' in pk else 'profiles/r01g_rocprof_summary.txt'}), "
-                                f"{max(1, round(lane_occ * 64))} of 64 lanes active (measured by the counted replay), {waves_per_simd} waves/SIMD, no arithmetic"
-                                if ceil else "libptubench.so not built"),
-                "peak_ns_per_wavestep": round(ceil[1], 2) if ceil else None,
+    lead = valu if (valu and (vmem["frac"] is None or valu["frac"] >= vmem["frac"])) else vmem
+    other = vmem if lead is valu else valu
+    roofline = {"kernel": "k_trace"}
+    roofline.update(lead)
+    roofline.update({
+                "second_resource": other,
                 "lane_occupancy": round(lane_occ, 4), "lane_steps_per_ray": round(S + T, 3),
                 "traffic": traffic, "traffic_source": (pmc or {}).get("source"),
                 "hbm_counter_frac": round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4) if traffic and sec > 0 else None,
@@ -346,7 +380,7 @@ def main():
                                     "algorithmic_bytes_per_launch": round(bytes_per_ray * rays_per_launch), "bytes_per_ray": round(bytes_per_ray, 1)},
                 "node_steps_per_ray": round(S, 3), "tri_tests_per_ray": round(T, 3),
                 "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_launch_ms, 4),
-                "trace_ms_total": round(cnt["ms_trace"], 3), "shade_ms_total": round(cnt["ms_shade"], 3)}
+                "trace_ms_total": round(cnt["ms_trace"], 3), "shade_ms_total": round(cnt["ms_shade"], 3)})
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:

@@ -103,7 +103,9 @@ typedef struct pt_counters {
 	uint64_t trace_launches;
 	uint64_t wave_iters;     /* only with PT_FLAG_COUNT_TRAVERSAL: wave-iterations of the traversal loop; (node_steps + tri_tests) /
 	                            (64 * wave_iters) = the share of lanes doing work per iteration */
-	uint64_t reserved[4];
+	uint64_t top_steps;      /* only with PT_FLAG_COUNT_TRAVERSAL: those of node_steps + tri_tests whose record came from the copy of
+	                            the tree top in LDS instead of global memory */
+	uint64_t reserved[3];
 } pt_counters;
 
 int pt_create(const pt_config *cfg, pt_ctx **out);
@@ -164,7 +166,7 @@ int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void 
 int pt_trace_closest_device_noalloc(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
 
 /* What pt_create settled on (no reference counterpart): info[0] frames per launch set, [1] pipelines, [2] queue stride
- * (slots), [3] slots per queue region, [4] paths per frame on this rank, [5] k_trace grid (blocks), [6..7] zero. */
+ * (slots), [3] slots per queue region, [4] paths per frame on this rank, [5] k_trace grid (blocks), [6] k_trace block size (threads), [7] bytes of the traversal blob's head that k_trace keeps in LDS. */
 int pt_get_info(const pt_ctx *ctx, uint32_t info[8]);
 
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);

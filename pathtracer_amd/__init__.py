@@ -49,7 +49,7 @@ class pt_scene_desc(ctypes.Structure):
 class pt_counters(ctypes.Structure):
     _fields_ = [("frames", c_uint64), ("paths", c_uint64), ("rays_primary", c_uint64), ("rays_shadow", c_uint64),
                 ("rays_bounce", c_uint64), ("node_steps", c_uint64), ("tri_tests", c_uint64), ("stack_spills", c_uint64),
-                ("ms_trace", c_double), ("ms_shade", c_double), ("trace_launches", c_uint64), ("wave_iters", c_uint64), ("reserved", c_uint64 * 4)]
+                ("ms_trace", c_double), ("ms_shade", c_double), ("trace_launches", c_uint64), ("wave_iters", c_uint64), ("top_steps", c_uint64), ("reserved", c_uint64 * 3)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -31,10 +31,31 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_NT_STORE(v, p) (*(p) = (v))
 #endif
 
+// The top of the tree lives in LDS: the first PT_TOP_BYTES of the traversal blob (build_traversal_blob puts the records
+// with the largest boxes there) are copied into every block's LDS at kernel start, and a lane whose record lies in that
+// range reads it with ds_read_b128 instead of global_load_dwordx4.  The kernel is bound by the vector-memory path's rate
+// of divergent 16-byte lane accesses (tools/ubench_gather.hip: 0.69 clk per lane and instruction whether they hit L1 or
+// not); every ray passes through the top levels, so this takes about half of those accesses off that path.
+// 0 = off (every record from global memory).
+#ifndef PT_TOP_BYTES
+#define PT_TOP_BYTES 16384
+#endif
+#if PT_TOP_BYTES
+#ifndef PT_SHORT_STACK
+#define PT_SHORT_STACK 12
+#endif
+#ifndef PT_TRACE_BLOCK
+#define PT_TRACE_BLOCK 1024 // 16 waves share one copy of the tree top: 16 * 3 KB of stacks + 16 KB = 64 KB, two blocks per CU
+#endif
+#define PT_TRACE_MIN_WAVES 8 // two such blocks per CU need 8 waves per SIMD: at most 64 VGPRs
+#else
 #define PT_SHORT_STACK 16
-#define PT_SPILL_STACK 48   // 16 + 48 = 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_BLOCK 256
+#define PT_TRACE_MIN_WAVES 7
+#endif
+#define PT_SPILL_STACK (64 - PT_SHORT_STACK) // together 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_WAVES (PT_TRACE_BLOCK / 64)
+#define PT_TOP_RECORDS (PT_TOP_BYTES / 64)
 // Work distribution.  A ray queue is cut into PT_SHARDS regions of `cap` slots (cap a multiple of 256); region r
 // holds count[r] live entries at slots [r*cap, r*cap + count[r]).  Every region has its own fill counter and its own
 // work-unit counter, each on a 128-byte line of its own, so no single word sees more than 1/PT_SHARDS of the
@@ -101,6 +122,7 @@ struct DevScene {
 	//     the two hit leaves of one step are ONE pending range.
 	const char *tblob;
 	uint32_t n_records;    // inner nodes; 0 = nothing to traverse (a root that is a leaf)
+	uint32_t tblob_bytes;
 	const float4 *tris;    // triangle i at tris[4*i] (shading)
 	const float4 *mats;    // material i at mats[3*i]
 	const float4 *spheres; // sphere i at spheres[2*i]
@@ -114,7 +136,7 @@ struct DevScene {
 
 // device control block shared by the kernels of one context
 struct DevCtl {
-	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, wave_iters, pad[10];
+	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, wave_iters, top_steps, pad[9];
 	uint32_t qcount[2][PT_SHARDS * PT_SHARD_STRIDE];             // live entries of region r of queue q at [q][r*32]
 	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE];                 // trace work-unit counters, zeroed before each trace launch
 	unsigned long long rays_bounce[PT_SHARDS * (PT_SHARD_STRIDE / 2)]; // per-region statistics, summed by the host
@@ -225,7 +247,7 @@ PT_DEV float shadow_kill_component(float y, float ro, float rd)
 // cur, tri, tri_end and the stack entries are byte offsets into the traversal blob: the address of either mode is
 // one select away, and no index is converted or range-checked here (pt_upload_scene proved every link).
 template <bool COUNT, bool GEN>
-__global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
+__global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(TraceArgs a)
 {
 	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK][64];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -235,6 +257,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	if (blockIdx.x == 0 && threadIdx.x < PT_SHARDS && a.zero_on_entry) a.zero_on_entry[threadIdx.x * PT_SHARD_STRIDE] = 0;
 
 	const char *__restrict__ blob = a.sc.tblob;
+#if PT_TOP_BYTES
+	__shared__ float4 s_top[PT_TOP_BYTES / 16];
+	const uint32_t top_bytes = a.sc.tblob_bytes < (uint32_t) PT_TOP_BYTES ? a.sc.tblob_bytes : (uint32_t) PT_TOP_BYTES; // a multiple of 64
+	for (uint32_t i = threadIdx.x; i < top_bytes / 16u; i += PT_TRACE_BLOCK) s_top[i] = ((const float4 *) blob)[i];
+	__syncthreads();
+#endif
 	const bool have_tree = a.sc.n_records != 0u;
 
 	// per-lane ray state
@@ -247,7 +275,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 	float best_u = 0.0f, best_v = 0.0f;
 	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
 	float t_kill = -__builtin_inff();  // shadow rays: an accepted hit with t <= t_kill ends the traversal
-	uint32_t n_steps = 0, n_tests = 0, n_spills = 0, n_iters = 0; // n_iters: iterations of the traversal loop (wave-uniform)
+	uint32_t n_steps = 0, n_tests = 0, n_spills = 0, n_iters = 0, n_top = 0; // n_iters: iterations of the traversal loop (wave-uniform)
 	// wave-uniform work state
 	bool exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0; // the unit this wave is handing out to its lanes
@@ -425,13 +453,32 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 		for (;;) {
 			// every active lane has work: pending triangles (T) or a record to visit (N); lanes retire at once
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
-			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form -- DESIGN.md
-			// "What was tried".)
+			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form, and again
+			// 1.5-5 % slower at 4/8/16 lanes after the tree top moved to LDS -- DESIGN.md "What was tried".)
 			if (COUNT) n_iters++;
 			if (active) {
 				const bool tmode = tri < tri_end;
-				const float4 *p = (const float4 *) (blob + (tmode ? tri : cur));
-				float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+				const uint32_t off = tmode ? tri : cur;
+				float4 q0, q1, q2, q3;
+#if PT_TOP_BYTES
+				// two exec-masked load groups (global_load_dwordx4 for the lanes below the top, ds_read_b128 for the others), issued
+				// back to back and awaited together.  The empty asm keeps the two branches apart: merged into one select of a generic
+				// pointer they become flat_load instructions, which take every lane through the vector-memory front end again.
+				if (off >= top_bytes) {
+					const float4 *p = (const float4 *) (blob + off);
+					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+				} else {
+					if (COUNT) n_top++;
+					const float4 *p = (const float4 *) ((const char *) s_top + off);
+					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+					asm volatile("" ::: "memory");
+				}
+#else
+				{
+					const float4 *p = (const float4 *) (blob + off);
+					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+				}
+#endif
 				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
 				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
@@ -490,11 +537,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, 7) void k_trace(TraceArgs a)
 		for (int o = 32; o > 0; o >>= 1) {
 			n_steps += __shfl_down(n_steps, o);
 			n_tests += __shfl_down(n_tests, o);
+			n_top += __shfl_down(n_top, o);
 		}
 		if (lane == 0) {
 			atomicAdd(&a.ctl->node_steps, (unsigned long long) n_steps);
 			atomicAdd(&a.ctl->tri_tests, (unsigned long long) n_tests);
 			atomicAdd(&a.ctl->wave_iters, (unsigned long long) n_iters);
+			atomicAdd(&a.ctl->top_steps, (unsigned long long) n_top);
 		}
 	}
 	{

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <queue>
 #include <vector>
 
 #include "../../include/pt355.h"
@@ -50,7 +51,7 @@ struct Pipe {
 // (padded to 256-byte granules) + PT_NOALLOC_MAX_BLOCKS x 4 waves x 48 levels x 64 lanes x 4 B = 24 MiB.  Every GPU the
 // library is loaded on holds its own copy at its own address until the process ends; the array's NAME is a host-side
 // stand-in only and is never handed to a kernel or a hip* call: the per-device address from hipGetSymbolAddress is.
-#define PT_NOALLOC_MAX_BLOCKS 512u
+#define PT_NOALLOC_MAX_BLOCKS (2048u / PT_TRACE_WAVES) /* 2048 waves: the whole chip at 8 waves per SIMD */
 struct NoAllocScratch {
 	DevCtl ctl;
 	unsigned char pad[(256u - sizeof(DevCtl) % 256u) % 256u];
@@ -448,12 +449,39 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 	auto child = [&](uint32_t i) { return i == 0 ? 1u : (uint32_t) nd[8 * i + 3]; };
 	for (uint32_t i = 0; i < n; i++) {
 		if (!inner(i)) continue;
-		rec_of[i] = n_inner++;
+		n_inner++;
 		const uint32_t ch = child(i);
 		for (uint32_t k = 0; k < 2; k++) {
 			if (claimed[ch + k]) return fail(c, PT_EINVAL, "pt_upload_scene: node %u is the child of two nodes (not a tree)", ch + k);
 			claimed[ch + k] = 1;
 		}
+	}
+	// Record order.  The first PT_TOP_RECORDS records are the part of the tree a ray is most likely to visit -- taken from
+	// the root in order of decreasing box area (the SAH's own visit probability) -- because k_trace keeps that prefix of
+	// the blob in LDS; the other records follow in node order.  The order is invisible to the traversal: links are byte
+	// offsets, and the root's record is first either way.
+	{
+		uint32_t next = 0;
+		if (n_inner) {
+			auto area = [&](uint32_t i) {
+				if (i == 0) return __builtin_inff();
+				const float *b = nd + 8 * (size_t) i;
+				const float dx = b[4] - b[0], dy = b[5] - b[1], dz = b[6] - b[2];
+				const float a = dx * dy + dy * dz + dz * dx;
+				return a == a ? a : 0.0f;
+			};
+			std::priority_queue<std::pair<float, uint32_t>> heap;
+			heap.push({area(0), 0u});
+			while (!heap.empty() && next < (uint32_t) PT_TOP_RECORDS) {
+				const uint32_t i = heap.top().second;
+				heap.pop();
+				rec_of[i] = next++;
+				for (uint32_t k = 0; k < 2; k++)
+					if (inner(child(i) + k)) heap.push({area(child(i) + k), child(i) + k});
+			}
+		}
+		for (uint32_t i = 0; i < n; i++)
+			if (inner(i) && rec_of[i] == 0xffffffffu) rec_of[i] = next++;
 	}
 	// the traversal stack holds one entry per level below the root: 16 in LDS + 48 spilled = the builder's max_depth
 	if (n_inner) {
@@ -576,6 +604,7 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 	if ((rc = upload(c, blob.data(), blob.size() * 4, &tb))) return rc; // hipMalloc is 256-B aligned: records sit on 64-B lines
 	d.tblob = tb;
 	d.n_records = n_records;
+	d.tblob_bytes = (uint32_t) (blob.size() * 4);
 	char *tmp = nullptr;
 	if ((rc = upload(c, s->tris, (size_t) s->n_tris * 64, &tmp))) return rc;
 	d.tris = (const float4 *) tmp;
@@ -900,7 +929,7 @@ int pt_get_info(const pt_ctx *c, uint32_t info[8])
 	if (!c || !info) return PT_EINVAL;
 	memset(info, 0, 8 * sizeof(uint32_t));
 	info[0] = c->max_batch; info[1] = c->n_pipes; info[2] = c->stride; info[3] = c->cap; info[4] = c->n_paths;
-	info[5] = (uint32_t) c->trace_grid;
+	info[5] = (uint32_t) c->trace_grid; info[6] = PT_TRACE_BLOCK; info[7] = PT_TOP_BYTES;
 	return PT_OK;
 }
 
@@ -922,7 +951,7 @@ int pt_get_counters(pt_ctx *c, pt_counters *out)
 			out->rays_bounce += h.rays_bounce[r * (PT_SHARD_STRIDE / 2)];
 		}
 		out->node_steps += h.node_steps; out->tri_tests += h.tri_tests; out->stack_spills += h.stack_spills;
-		out->wave_iters += h.wave_iters;
+		out->wave_iters += h.wave_iters; out->top_steps += h.top_steps;
 	}
 	out->ms_trace = c->ms_trace; out->ms_shade = c->ms_shade; out->trace_launches = c->trace_launches;
 	return PT_OK;

@@ -297,7 +297,7 @@ int pt_group_get_counters(pt_group *g, pt_counters *out)
 		pt_counters c;
 		G_PT(g, i, pt_get_counters(g->member[i], &c));
 		out->paths += c.paths; out->rays_primary += c.rays_primary; out->rays_shadow += c.rays_shadow; out->rays_bounce += c.rays_bounce;
-		out->node_steps += c.node_steps; out->tri_tests += c.tri_tests; out->stack_spills += c.stack_spills; out->wave_iters += c.wave_iters;
+		out->node_steps += c.node_steps; out->tri_tests += c.tri_tests; out->stack_spills += c.stack_spills; out->wave_iters += c.wave_iters; out->top_steps += c.top_steps;
 		out->ms_trace += c.ms_trace; out->ms_shade += c.ms_shade; out->trace_launches += c.trace_launches; // sums over devices that ran concurrently
 	}
 	out->frames = g->frames_total;

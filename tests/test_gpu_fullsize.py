@@ -35,7 +35,38 @@ def test_config1_bunny_oren_nayar_1080p(pt, ol):
     """configs[1]: bunny-class mesh (69,463 triangles after the shell), Lambert walls + Oren-Nayar mesh, 1920x1080."""
     scene = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
     cnt, ocnt = _vs_oracle(pt, ol, scene, W, H, 2)
-    assert cnt["stack_spills"] == 0 and ocnt["max_stack"] <= 16
+    # the reference's 16-slot stack is deep enough for this tree; the kernel keeps 12 levels per lane in LDS and spills the
+    # (rare, exact) rest to its HBM tail
+    assert ocnt["max_stack"] <= 16 and cnt["stack_spills"] < 1e-5 * (cnt["rays_shadow"] + cnt["rays_bounce"])
+
+
+def test_tree_top_in_lds_is_counted_and_changes_nothing(pt, ol):
+    """k_trace serves the head of the traversal blob (pt_get_info [7] bytes) from LDS: a Cornell box fits entirely, so
+    every step is an LDS step; on the bunny about half are; hits equal the oracle's either way (same kernel as above)."""
+    info_top = None
+    for scene, all_lds in ((pt.Scene.cornell(), True), (pt.Scene.bunny(freq=59, target_tris=69451, seed=1), False)):
+        c = pt.PathTracer(256, 256, flags=pt.PT_FLAG_COUNT_TRAVERSAL | pt.PT_FLAG_TRACE_DEAD_PATHS | pt.PT_FLAG_SHADOW_FULL_TRAVERSAL)
+        try:
+            c.upload_scene(scene)
+            c.set_camera(pt.default_camera())
+            seeds = pt.frame_seeds(0, 2)
+            c.render(0, seeds, 5)
+            img, cnt = c.read_framebuffer(), c.counters()
+            info_top = int(c.info[7])
+        finally:
+            c.close()
+        ref, ocnt = ol.render(ol.scene_from_desc(scene.desc()), pt.default_camera(), 256, 256, seeds, threads=8)
+        assert (img.view(np.uint32) == ref.view(np.uint32)).all()
+        steps = cnt["node_steps"] + cnt["tri_tests"]
+        assert (cnt["node_steps"], cnt["tri_tests"]) == (ocnt["node_steps"], ocnt["tri_tests"])
+        d = scene.desc()
+        blob = 64 * ((d.n_nodes - 1) // 2 + d.n_tris)
+        if info_top == 0:
+            assert cnt["top_steps"] == 0
+        elif all_lds:
+            assert blob <= info_top and cnt["top_steps"] == steps
+        else:
+            assert blob > info_top and 0.25 * steps < cnt["top_steps"] < 0.9 * steps
 
 
 def test_config2_bunny_ggx_gold_1080p(pt, ol):

@@ -8,7 +8,10 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 BIN=./pathtracer_amd/ptbench
+if [ -z "${UBENCH_ARGS:-}" ]; then   # UBENCH_ARGS="miss_l1 miss_l2 lanes waves": only the micro-benchmark calibration at the bottom
 timeout -k 10 120 $BIN $FRAMES > $OUT/plain.json || exit 1
+# the same frames with PT_FLAG_COUNT_TRAVERSAL (4): node-pair visits, triangle tests and wave-iterations -> lane-steps per launch
+timeout -k 10 180 $BIN $FRAMES 1920 1080 0 4 > $OUT/counted.json || exit 1
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BIN $FRAMES > $OUT/stats.log 2>&1 || exit 1
 pass() { # name counters...
 	local name=$1; shift
@@ -21,3 +24,15 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 python3 tools/prof_summary.py $OUT $TAG > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+else
+echo "$UBENCH_ARGS" > $OUT/ubench_args.txt
+fi
+# calibration of bench.py's gather ceiling: the micro-benchmark at the kernel's per-lane-step miss rates (written by
+# prof_summary.py), under the same cache counters -- its own requests per lane-step should come out at those rates
+if [ -s $OUT/ubench_args.txt ] && [ -x ./pathtracer_amd/ubench_gather ]; then
+	ARGS=$(cat $OUT/ubench_args.txt)
+	timeout -k 10 120 ./pathtracer_amd/ubench_gather tiers $ARGS > $OUT/ubench_plain.txt || exit 1
+	timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/ubench -o p -- ./pathtracer_amd/ubench_gather tiers $ARGS > $OUT/ubench.log 2>&1 || { echo "ubench pass failed"; tail -3 $OUT/ubench.log; exit 1; }
+	python3 tools/prof_summary.py $OUT $TAG ubench > $OUT/${TAG}_ubench_calibration.txt 2>&1
+	cat $OUT/${TAG}_ubench_calibration.txt
+fi

@@ -9,6 +9,43 @@ from collections import defaultdict
 
 out = sys.argv[1]
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+mode = sys.argv[3] if len(sys.argv) > 3 else "kernels"
+
+# queue columns k_trace streams per ray besides the traversal blob (kernels_trace.h refill): valid flag 4 B + ray 24 B, + 12 B
+# of target for shadow rays (about half of the rays); coalesced, 128-B requests that miss L1 and L2 alike
+STREAM_READ_REQ_PER_RAY = (4 + 24 + 6) / 128.0
+
+
+def ubench_calibration():
+    """The micro-benchmark's own cache counters per lane-step, next to the rates it was asked to reproduce."""
+    want = open(os.path.join(out, "ubench_args.txt")).read().split()
+    line = open(os.path.join(out, "ubench_plain.txt")).read().strip()
+    m1, m2, lanes, wps = float(want[0]), float(want[1]), int(want[2]), int(want[3])
+    per_launch = 256.0 * wps * 4 * lanes * 2000.0
+    a, n = defaultdict(float), defaultdict(int)
+    for f in glob.glob(os.path.join(out, "ubench", "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "k_gather_tiers" in row["Kernel_Name"]:
+                a[row["Counter_Name"]] += float(row["Counter_Value"])
+                n[row["Counter_Name"]] += 1
+    print("== gather-ceiling micro-benchmark (tools/ubench_gather.hip, k_gather_tiers) under the cache counters")
+    print(line)
+    print(f"asked for: {m1:.4f} TCP->TCC read requests and {m2:.4f} TCC->fabric read requests per lane-step (the trace kernel's, "
+          f"{tag}_pmc_traffic.json k_trace_all), {lanes} lanes, {wps} waves/SIMD; {per_launch:.0f} lane-steps per launch")
+    for c in sorted(a):
+        print(f"   {c:36s} {a[c] / max(n[c], 1):16.1f} per launch (n={n[c]})  = {a[c] / max(n[c], 1) / per_launch:8.4f} per lane-step")
+    g = lambda c: a[c] / max(n[c], 1) if c in a else None
+    if g("TCP_TCC_READ_REQ_sum") is not None:
+        print(f"   -> measured TCP->TCC read requests per lane-step {g('TCP_TCC_READ_REQ_sum') / per_launch:.4f}  (asked {m1:.4f})")
+    if g("TCC_EA0_RDREQ_sum") is not None:
+        print(f"   -> measured TCC->fabric read requests per lane-step {g('TCC_EA0_RDREQ_sum') / per_launch:.4f}  (asked {m2:.4f})")
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum") and g("TCP_TCC_READ_REQ_sum") is not None:
+        print(f"   -> TCP miss share per access {g('TCP_TCC_READ_REQ_sum') / g('TCP_TOTAL_CACHE_ACCESSES_sum') * 100:.1f} %")
+
+
+if mode == "ubench":
+    ubench_calibration()
+    sys.exit(0)
 
 
 def short(name):
@@ -79,6 +116,11 @@ for k in kern:
     tot, req = acc[k].get("TCP_TOTAL_CACHE_ACCESSES_sum"), acc[k].get("TCP_TCC_READ_REQ_sum")
     if tot:
         kern[k]["l1_miss_share"] = (req or 0.0) / tot
+    for c, name in (("TCP_TCC_READ_REQ_sum", "tcp_tcc_read_req"), ("TCC_EA0_RDREQ_sum", "tcc_ea_rdreq"), ("TCP_TOTAL_CACHE_ACCESSES_sum", "tcp_total_cache_accesses"),
+                    ("SQ_INSTS_VALU", "sq_insts_valu"), ("SQ_INSTS_SALU", "sq_insts_salu"), ("SQ_THREAD_CYCLES_VALU", "sq_thread_cycles_valu"),
+                    ("SQ_ACTIVE_INST_VALU", "sq_active_inst_valu")):
+        if c in acc[k]:
+            kern[k][name] = acc[k][c] / max(cnt[k][c], 1)
     hit, miss = acc[k].get("TCC_HIT_sum"), acc[k].get("TCC_MISS_sum")
     if hit is not None and miss is not None and hit + miss > 0:
         kern[k]["l2_hit_rate"] = hit / (hit + miss)
@@ -93,11 +135,35 @@ tr = [k for k in kern if k.startswith("k_trace") and "count" not in k]
 if tr:
     n = sum(kern[k]["launches_profiled"] for k in tr) or 1
     allk = {"launches_profiled": n}
-    for f in ("fetch_size_kb", "write_size_kb", "hbm_bytes_per_launch", "l1_miss_share", "l2_hit_rate", "avg_launch_ms_kernel_trace"):
+    for f in ("fetch_size_kb", "write_size_kb", "hbm_bytes_per_launch", "l1_miss_share", "l2_hit_rate", "avg_launch_ms_kernel_trace",
+              "tcp_tcc_read_req", "tcc_ea_rdreq", "tcp_total_cache_accesses", "sq_insts_valu", "sq_insts_salu", "sq_thread_cycles_valu",
+              "sq_active_inst_valu"):
         if all(f in kern[k] for k in tr):
             allk[f] = sum(kern[k][f] * kern[k]["launches_profiled"] for k in tr) / n
     if plain.get("trace_launches"):
         allk["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
+    # per lane-step (one lane fetching one 64-B record): cache-miss requests of the record fetches alone, i.e. after
+    # taking out the streamed queue columns -- what bench.py hands to the gather-ceiling micro-benchmark
+    try:
+        counted = json.loads(open(os.path.join(out, "counted.json")).read().strip().splitlines()[-1])
+    except Exception:
+        counted = {}
+    if counted.get("wave_iters") and counted.get("trace_launches") and "tcp_tcc_read_req" in allk and "tcc_ea_rdreq" in allk:
+        steps = (counted["node_steps"] + counted["tri_tests"]) / counted["trace_launches"]
+        top = counted.get("top_steps", 0) / counted["trace_launches"]  # served from the LDS copy of the tree top: never on the vector-memory path
+        gsteps = max(steps - top, 1.0)
+        rays = counted["rays"] / counted["trace_launches"]
+        primary = 1920.0 * 1080.0 * counted["frames"] / counted["trace_launches"]  # fused primary stage: rays generated, nothing streamed in
+        stream = STREAM_READ_REQ_PER_RAY * max(rays - primary, 0.0)
+        allk["lane_steps_per_launch"] = steps
+        allk["global_lane_steps_per_launch"] = gsteps
+        allk["lane_occupancy"] = (counted["node_steps"] + counted["tri_tests"]) / (64.0 * counted["wave_iters"])
+        allk["record_miss_l1_per_lane_step"] = max(allk["tcp_tcc_read_req"] - stream, 0.0) / gsteps  # per GLOBAL lane-step
+        allk["record_miss_l2_per_lane_step"] = max(allk["tcc_ea_rdreq"] - stream, 0.0) / gsteps
+        allk["streamed_read_requests_assumed"] = stream
+        with open(os.path.join(out, "ubench_args.txt"), "w") as fh:
+            fh.write(f"{allk['record_miss_l1_per_lane_step']:.4f} {allk['record_miss_l2_per_lane_step']:.4f} "
+                     f"{max(1, round(allk['lane_occupancy'] * 64 * gsteps / steps))} 8\n")
     kern["k_trace_all"] = allk
 if False and "k_trace" in kern and plain.get("trace_launches"):
     kern["k_trace"]["rays_per_launch"] = plain["rays"] / plain["trace_launches"]

@@ -52,10 +52,10 @@ int main(int argc, char **argv)
 	pt_get_counters(c, &k);
 	const double rays = (double) (k.rays_primary + k.rays_shadow + k.rays_bounce);
 	printf("{\"tris\": %u, \"nodes\": %u, \"frames\": %u, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"rays\": %.0f, "
-	       "\"ms_trace\": %.3f, \"ms_shade\": %.3f, \"trace_launches\": %llu, \"node_steps\": %llu, \"tri_tests\": %llu, \"spills\": %llu}\n",
+	       "\"ms_trace\": %.3f, \"ms_shade\": %.3f, \"trace_launches\": %llu, \"node_steps\": %llu, \"tri_tests\": %llu, \"spills\": %llu, \"wave_iters\": %llu, \"top_steps\": %llu}\n",
 	       d.n_tris, d.n_nodes, frames, dt / frames * 1e3, rays / dt / 1e6, rays, k.ms_trace, k.ms_shade,
 	       (unsigned long long) k.trace_launches, (unsigned long long) k.node_steps, (unsigned long long) k.tri_tests,
-	       (unsigned long long) k.stack_spills);
+	       (unsigned long long) k.stack_spills, (unsigned long long) k.wave_iters, (unsigned long long) k.top_steps);
 	pt_destroy(c);
 	pth_scene_destroy(s);
 	free(seeds);
