@@ -36,9 +36,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-# k_trace's cache-miss read requests per record fetch on the bunny workload (profiles/r02c_pmc_traffic.json, k_trace_all);
+# k_trace's cache-miss read requests per global record fetch on the bunny workload (profiles/r02d_pmc_traffic.json, k_trace_all);
 # used for the gather ceiling only when the workload being benched has no PMC passes of its own
-DEFAULT_MISS_L1, DEFAULT_MISS_L2 = 0.26, 0.04
+DEFAULT_MISS_L1, DEFAULT_MISS_L2 = 0.57, 0.11
 
 
 def make_scene(pt, name):
@@ -345,7 +345,7 @@ def main():
             "peak_source": ("measured live by pathtracer_amd/libptubench.so (tools/ubench_gather.hip: ptu_gather_ceiling): dependent 64-B "
                             f"record gathers, 4 x dwordx4 per lane-step, at the kernel's cache-miss requests per record fetch -- {miss_l1:.3f} "
                             f"TCP->TCC and {miss_l2:.3f} TCC->fabric read requests per global lane-step ("
-                            f"{pmc_name if have_pmc else 'no PMC passes for this workload: the bunny workload figures'}), "
+                            f"{pmc_name if have_pmc else 'no PMC passes for this workload: the bunny workload figures of profiles/r02d_pmc_traffic.json'}), "
                             f"{gather_lanes} of 64 lanes gathering per wave-step (counted replay), {waves_per_simd} waves/SIMD, no arithmetic"
                             if ceil else "libptubench.so not built"),
             "record_miss_l1_per_lane_step": round(miss_l1, 4), "record_miss_l2_per_lane_step": round(miss_l2, 4),

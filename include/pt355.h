@@ -157,7 +157,7 @@ int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void 
 
 /* No counterpart in the reference.  pt_trace_closest_device for callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernel, same arguments, same hit records; the
- * kernel's scratch (work-unit counters and statistics block, traversal-stack spill tail: 24 MiB) is a file-scope
+ * kernel's scratch (work-unit counters and statistics block, traversal-stack spill tail: 26 MiB) is a file-scope
  * device array that every GPU the library runs on holds until the process ends, and the call makes no hipMalloc /
  * hipFree / event creation.  At most PT_NOALLOC_MAX_RAYS rays per call (PT_EINVAL beyond).  All calls on one GPU share
  * that GPU's array: calls that overlap on one GPU (any contexts, any streams) race; back-to-back calls on the

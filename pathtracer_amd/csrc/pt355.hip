@@ -48,7 +48,7 @@ struct Pipe {
 // ---- scratch of the allocation-free trace entry (pt_trace_closest_device_noalloc).  What k_trace needs beyond its
 // inputs and outputs -- the control block (work-unit counters, statistics) and the traversal-stack spill tail of every
 // wave of a capped grid -- lives in ONE file-scope device array instead of hipMalloc'ed memory: 41,088 B of DevCtl
-// (padded to 256-byte granules) + PT_NOALLOC_MAX_BLOCKS x 4 waves x 48 levels x 64 lanes x 4 B = 24 MiB.  Every GPU the
+// (padded to 256-byte granules) + 2,048 waves (PT_NOALLOC_MAX_BLOCKS blocks) x 52 spill levels x 64 lanes x 4 B = 26 MiB.  Every GPU the
 // library is loaded on holds its own copy at its own address until the process ends; the array's NAME is a host-side
 // stand-in only and is never handed to a kernel or a hip* call: the per-device address from hipGetSymbolAddress is.
 #define PT_NOALLOC_MAX_BLOCKS (2048u / PT_TRACE_WAVES) /* 2048 waves: the whole chip at 8 waves per SIMD */
