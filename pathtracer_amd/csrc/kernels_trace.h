@@ -260,7 +260,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 #if PT_TOP_BYTES
 	__shared__ float4 s_top[PT_TOP_BYTES / 16];
 	const uint32_t top_bytes = a.sc.tblob_bytes < (uint32_t) PT_TOP_BYTES ? a.sc.tblob_bytes : (uint32_t) PT_TOP_BYTES; // a multiple of 64
-	for (uint32_t i = threadIdx.x; i < top_bytes / 16u; i += PT_TRACE_BLOCK) s_top[i] = ((const float4 *) blob)[i];
+	// LDS image: the four 16-byte pieces of a record in four planes ([piece][record]), so that one ds_read_b128 of the wave
+	// (piece j of 64 different records, 16 B apart) spreads over all 64 banks; kept as 64-byte records it would touch only
+	// the 16 banks of its piece
+	for (uint32_t i = threadIdx.x; i < top_bytes / 16u; i += PT_TRACE_BLOCK) s_top[(i & 3u) * PT_TOP_RECORDS + (i >> 2)] = ((const float4 *) blob)[i];
 	__syncthreads();
 #endif
 	const bool have_tree = a.sc.n_records != 0u;
@@ -469,8 +472,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
 				} else {
 					if (COUNT) n_top++;
-					const float4 *p = (const float4 *) ((const char *) s_top + off);
-					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+					const float4 *p = (const float4 *) ((const char *) s_top + (off >> 2));
+					q0 = p[0]; q1 = p[PT_TOP_RECORDS]; q2 = p[2 * PT_TOP_RECORDS]; q3 = p[3 * PT_TOP_RECORDS];
 					asm volatile("" ::: "memory");
 				}
 #else
