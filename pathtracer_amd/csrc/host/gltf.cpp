@@ -20,6 +20,7 @@
 // Where the reference would crash (missing indices / normals, out-of-range index) this loader returns an error.
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -480,75 +481,196 @@ int decode_image_rgb8(const uint8_t *d, size_t n, std::vector<uint8_t> &rgb, int
 	return decode_png_rgb8(d, n, rgb, w, h, channels);
 }
 
-// Separable resample to 512 x 512 with the filters stbir_resize_uint8 picks by default (stb_image_resize.h: Catmull-Rom when
-// enlarging, Mitchell-Netravali with the support widened by 1/scale when shrinking, clamped edges, linear colour space, 8-bit
-// rounding by +0.5).  Own evaluation: it is NOT bit-pinned to stb's accumulation order -- tests bound the difference
-// against the reference's own stb build (tests/test_gltf_loader.py); images that are 512 x 512 already pass through untouched.
-float catmull_rom(float x)
-{
-	x = fabsf(x);
-	if (x < 1.0f) return 1.0f - x * x * (2.5f - 1.5f * x);
-	if (x < 2.0f) return 2.0f - x * (4.0f + x * (0.5f * x - 2.5f));
-	return 0.0f;
-}
-float mitchell(float x)
-{
-	x = fabsf(x);
-	if (x < 1.0f) return (16.0f + x * x * (21.0f * x - 36.0f)) / 18.0f;
-	if (x < 2.0f) return (32.0f + x * (-60.0f + x * (36.0f - 7.0f * x))) / 18.0f;
-	return 0.0f;
-}
-void resample_axis(const std::vector<float> &src, int sw, int sh, int ch, std::vector<float> &dst, int dw, bool horizontal)
-{
-	// resamples the first axis (width) of a [sh][sw][ch] image when horizontal, else the second (height given as sw/sh swapped by the caller)
-	(void) horizontal;
-	const float scale = (float) dw / (float) sw;
-	const bool up = scale > 1.0f;
-	const float support = up ? 2.0f : 2.0f / scale;
-	dst.assign((size_t) sh * dw * ch, 0.0f);
-	std::vector<float> wts;
-	for (int x = 0; x < dw; x++) {
-		const float center = ((float) x + 0.5f) / scale; // in source pixels
-		const int lo = (int) floorf(center - support + 0.5f), hi = (int) floorf(center + support - 0.5f);
-		wts.assign((size_t) (hi - lo + 1), 0.0f);
-		float total = 0.0f;
-		for (int k = lo; k <= hi; k++) {
-			const float dx = ((float) k + 0.5f) - center;
-			const float wv = up ? catmull_rom(dx) : mitchell(dx * scale) * scale;
-			wts[(size_t) (k - lo)] = wv;
-			total += wv;
+// stbir_resize_uint8(in, w, h, 0, out, 512, 512, 0, 3) as src/loader.cpp:224-232 calls it (stb_image_resize v0.97), restated so
+// that every float operation happens in the same order: clamped edges, linear colour space, Catmull-Rom when an axis is
+// enlarged and Mitchell-Netravali when it is not (an axis of exactly 512 is "not enlarged": it is filtered, not copied),
+// coefficients normalised per output pixel, gather form for enlarged axes and scatter form (input pixel -> the output
+// pixels it touches) for the others, horizontal pass first, vertical accumulation in scanline order, bytes by
+// (int)(saturate(v) * 255 + 0.5).  The reference's ring buffers only cache rows; dense accumulators give the same sums.
+// Even its one out-of-bounds habit is kept: a scatter coefficient group is 4 wide but 5 values can be written, the 5th
+// landing in the next group's first slot until that group is computed (stb_image_resize.h:1092-1124, 1126-1199).
+// tests/test_gltf_loader.py::test_resize_to_512 compares with the reference's own stb build byte for byte.
+struct ResizeAxis {
+	bool up = false;
+	float scale = 1.0f;
+	int in_size = 0, out_size = 0, margin = 0, coef_w = 4, n_contrib = 0;
+	std::vector<int> n0, n1;
+	std::vector<float> coef; // [n_contrib][coef_w], flat, zero-padded at the end
+	float kernel(float x) const
+	{
+		x = (float) fabs(x);
+		if (up) { // Catmull-Rom (stb_image_resize.h:811-823)
+			if (x < 1.0f) return 1 - x * x * (2.5f - 1.5f * x);
+			if (x < 2.0f) return 2 - x * (4 + x * (0.5f * x - 2.5f));
+			return 0.0f;
 		}
-		for (float &wv : wts) wv /= total;
-		for (int y = 0; y < sh; y++)
-			for (int c = 0; c < ch; c++) {
-				float acc = 0.0f;
-				for (int k = lo; k <= hi; k++) {
-					const int kk = k < 0 ? 0 : (k >= sw ? sw - 1 : k);
-					acc += wts[(size_t) (k - lo)] * src[((size_t) y * sw + kk) * ch + c];
-				}
-				dst[((size_t) y * dw + x) * ch + c] = acc;
-			}
+		if (x < 1.0f) return (16 + x * x * (21 * x - 36)) / 18; // Mitchell (:825-837)
+		if (x < 2.0f) return (32 + x * (-60 + x * (36 - 7 * x))) / 18;
+		return 0.0f;
 	}
-}
+	void build(int in, int out)
+	{
+		in_size = in; out_size = out;
+		scale = ((float) out / in) / (1.0f - 0.0f);
+		up = scale > 1;
+		const float support = 2.0f;
+		const int pixel_width = up ? (int) ceil(support * 2) : (int) ceil(support * 2 / scale);
+		margin = pixel_width / 2;
+		coef_w = (int) ceil(support * 2);
+		n_contrib = up ? out : in + margin * 2;
+		n0.assign((size_t) n_contrib, 0); n1.assign((size_t) n_contrib, 0);
+		coef.assign((size_t) n_contrib * coef_w + 8, 0.0f);
+		const float shift = 0.0f;
+		if (up) {
+			const float out_radius = support * scale;
+			for (int n = 0; n < n_contrib; n++) {
+				const float out_center = (float) n + 0.5f;
+				const float lo = (out_center - out_radius + shift) / scale, hi = (out_center + out_radius + shift) / scale;
+				const float in_center_of_out = (out_center + shift) / scale;
+				int first = (int) (floor(lo + 0.5)), last = (int) (floor(hi - 0.5));
+				float *g = &coef[(size_t) n * coef_w];
+				float total = 0;
+				n0[n] = first; n1[n] = last;
+				for (int i = 0; i <= last - first; i++) {
+					const float in_pixel_center = (float) (i + first) + 0.5f;
+					g[i] = kernel(in_center_of_out - in_pixel_center);
+					if (i == 0 && !g[i]) { n0[n] = ++first; i--; continue; } // a leading zero is dropped, slot 0 rewritten
+					total += g[i];
+				}
+				const float filter_scale = 1 / total;
+				for (int i = 0; i <= last - first; i++) g[i] *= filter_scale;
+				for (int i = last - first; i >= 0; i--) {
+					if (g[i]) break;
+					n1[n] = n0[n] + i - 1;
+				}
+			}
+			return;
+		}
+		const float in_radius = support / scale;
+		for (int n = 0; n < n_contrib; n++) {
+			const float in_center = (float) (n - margin) + 0.5f;
+			const float lo = (in_center - in_radius) * scale - shift, hi = (in_center + in_radius) * scale - shift;
+			const float out_center_of_in = in_center * scale - shift;
+			const int first = (int) (floor(lo + 0.5)), last = (int) (floor(hi - 0.5));
+			float *g = &coef[(size_t) n * coef_w];
+			n0[n] = first; n1[n] = last;
+			for (int i = 0; i <= last - first; i++) {
+				const float out_pixel_center = (float) (i + first) + 0.5f;
+				g[i] = kernel((out_pixel_center - out_center_of_in) * 1.0f) * scale; // kernel(x, scale): Mitchell ignores the scale argument
+			}
+			for (int i = last - first; i >= 0; i--) {
+				if (g[i]) break;
+				n1[n] = n0[n] + i - 1;
+			}
+		}
+		// per output pixel: the coefficients of every input pixel reaching it sum to 1
+		for (int i = 0; i < out_size; i++) {
+			float total = 0;
+			for (int j = 0; j < n_contrib; j++) {
+				if (i >= n0[j] && i <= n1[j]) total += coef[(size_t) j * coef_w + (i - n0[j])];
+				else if (i < n0[j]) break;
+			}
+			const float sc = 1 / total;
+			for (int j = 0; j < n_contrib; j++) {
+				if (i >= n0[j] && i <= n1[j]) coef[(size_t) j * coef_w + (i - n0[j])] *= sc;
+				else if (i < n0[j]) break;
+			}
+		}
+		// leading zeros and outputs left of the image are skipped, the group shifted down accordingly
+		for (int j = 0; j < n_contrib; j++) {
+			int skip = 0;
+			while ((size_t) j * coef_w + skip < coef.size() && coef[(size_t) j * coef_w + skip] == 0) skip++;
+			n0[j] += skip;
+			while (n0[j] < 0) { n0[j]++; skip++; }
+			const int range = n1[j] - n0[j] + 1, mx = coef_w < range ? coef_w : range;
+			for (int i = 0; i < mx; i++) {
+				if (i + skip >= coef_w) break;
+				coef[(size_t) j * coef_w + i] = coef[(size_t) j * coef_w + i + skip];
+			}
+		}
+		for (int j = 0; j < n_contrib; j++) n1[j] = n1[j] < out_size - 1 ? n1[j] : out_size - 1;
+	}
+};
+
 void resize_rgb8_512(const std::vector<uint8_t> &in, int w, int h, uint8_t *out)
 {
-	if (w == 512 && h == 512) { memcpy(out, in.data(), (size_t) 512 * 512 * 3); return; }
-	std::vector<float> a((size_t) w * h * 3), b, t, c;
-	for (size_t i = 0; i < a.size(); i++) a[i] = (float) in[i] / 255.0f;
-	resample_axis(a, w, h, 3, b, 512, true); // [h][512][3]
-	// transpose so that the height becomes the fast axis, resample, transpose back
-	t.resize(b.size());
-	for (int y = 0; y < h; y++)
-		for (int x = 0; x < 512; x++)
-			for (int k = 0; k < 3; k++) t[((size_t) x * h + y) * 3 + k] = b[((size_t) y * 512 + x) * 3 + k];
-	resample_axis(t, h, 512, 3, c, 512, false); // [512 (x)][512 (y)][3]
-	for (int y = 0; y < 512; y++)
-		for (int x = 0; x < 512; x++)
-			for (int k = 0; k < 3; k++) {
-				float v = c[((size_t) x * 512 + y) * 3 + k];
-				v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-				out[((size_t) y * 512 + x) * 3 + k] = (uint8_t) (int) (v * 255.0f + 0.5f);
+	if (w == 512 && h == 512) { memcpy(out, in.data(), (size_t) 512 * 512 * 3); return; } // loader.cpp:222: no resize call at all
+	const int ch = 3, ow = 512, oh = 512;
+	ResizeAxis H, V;
+	H.build(w, ow);
+	V.build(h, oh);
+	std::vector<float> decode((size_t) (w + 2 * H.margin) * ch), hrow((size_t) ow * ch);
+	float *const dec = decode.data() + (size_t) H.margin * ch; // index 0 = first image pixel, negative indices = the left margin
+	// input scanline n (clamped to the image) decoded to floats and resampled horizontally into hrow
+	auto horizontal = [&](int n) {
+		const int row = n < 0 ? 0 : (n >= h ? h - 1 : n);
+		const uint8_t *src = in.data() + (size_t) row * w * ch;
+		for (int x = -H.margin; x < w + H.margin; x++) {
+			const int xx = x < 0 ? 0 : (x >= w ? w - 1 : x);
+			for (int c = 0; c < ch; c++) dec[x * ch + c] = ((float) src[xx * ch + c]) / 255.0f;
+		}
+		std::fill(hrow.begin(), hrow.end(), 0.0f);
+		if (H.up) {
+			for (int x = 0; x < ow; x++) {
+				int counter = 0;
+				for (int k = H.n0[x]; k <= H.n1[x]; k++) {
+					const float cf = H.coef[(size_t) x * H.coef_w + counter++];
+					for (int c = 0; c < ch; c++) hrow[(size_t) x * ch + c] += dec[k * ch + c] * cf;
+				}
 			}
+		} else {
+			for (int x = 0; x < w + 2 * H.margin; x++) {
+				const int in_x = x - H.margin;
+				for (int k = H.n0[x]; k <= H.n1[x]; k++) {
+					const float cf = H.coef[(size_t) x * H.coef_w + k - H.n0[x]];
+					for (int c = 0; c < ch; c++) hrow[(size_t) k * ch + c] += dec[in_x * ch + c] * cf;
+				}
+			}
+		}
+	};
+	auto encode = [&](const float *row, int y) {
+		for (int i = 0; i < ow * ch; i++) {
+			float v = row[i];
+			v = v < 0 ? 0 : (v > 1 ? 1 : v);
+			out[(size_t) y * ow * ch + i] = (uint8_t) (int) ((v * 255.0f) + 0.5);
+		}
+	};
+	if (V.up) {
+		// every needed scanline is resampled once (the reference keeps them in a ring buffer), then each output row sums its
+		// contributors in order
+		std::vector<std::vector<float>> cache((size_t) h + 2 * V.margin + 8);
+		const int base = V.margin + 4;
+		std::vector<float> acc((size_t) ow * ch);
+		for (int y = 0; y < oh; y++) {
+			std::fill(acc.begin(), acc.end(), 0.0f);
+			int counter = 0;
+			for (int k = V.n0[y]; k <= V.n1[y]; k++) {
+				std::vector<float> &r = cache[(size_t) (k + base)];
+				if (r.empty()) { horizontal(k); r = hrow; }
+				const float cf = V.coef[(size_t) y * V.coef_w + counter++];
+				for (int i = 0; i < ow * ch; i++) acc[i] += r[i] * cf;
+			}
+			encode(acc.data(), y);
+			for (int k = 0; k + 1 < V.n0[y] + base && k < (int) cache.size(); k++) if (!cache[(size_t) k].empty()) std::vector<float>().swap(cache[(size_t) k]);
+		}
+		return;
+	}
+	std::vector<float> acc((size_t) oh * ow * ch, 0.0f);
+	const float in_radius = 2.0f / V.scale;
+	for (int y = -V.margin; y < h + V.margin; y++) {
+		const float in_center = (float) y + 0.5f;
+		const float lo = (in_center - in_radius) * V.scale - 0.0f, hi = (in_center + in_radius) * V.scale - 0.0f;
+		const int first = (int) (floor(lo + 0.5)), last = (int) (floor(hi - 0.5));
+		if (last < 0 || first >= oh) continue;
+		horizontal(y);
+		const int j = y + V.margin;
+		for (int k = V.n0[j]; k <= V.n1[j]; k++) {
+			const float cf = V.coef[(size_t) j * V.coef_w + k - V.n0[j]];
+			float *r = &acc[(size_t) k * ow * ch];
+			for (int i = 0; i < ow * ch; i++) r[i] += hrow[i] * cf;
+		}
+	}
+	for (int y = 0; y < oh; y++) encode(&acc[(size_t) y * ow * ch], y);
 }
 
 } // namespace

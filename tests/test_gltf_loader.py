@@ -3,11 +3,12 @@
 tests/golden/ref_gltf.npz by tests/golden/make_golden_gltf.py) on the texture-less .glb files under tests/golden/gltf/.
 Bit-exact: fat triangles, material indices, MaterialGLSL bytes, TriangleGLSL bytes, as loaded and after the scene set-up
 of src/main.cpp:26-29.  The textured path cannot run through the reference's loader without a GL context; its two image
-steps are checked against the reference's stb build where that exists (build container) -- "parity unpinned" on the
-GPU box, where only their own properties are tested."""
+steps (decode of PNG / JPEG, resize to 512 x 512) equal the reference's own stb build byte for byte: against committed
+outputs of that build (tests/golden/ref_jpeg.npz, ref_resize.npz) everywhere, and live where the build exists."""
 import ctypes
 import os
 import struct
+import sys
 import zlib
 
 import numpy as np
@@ -282,7 +283,7 @@ def _resize(pt, img):
     return out
 
 
-def test_resize_to_512(pt, ol):
+def test_resize_to_512(pt, ol, golden):
     rng = np.random.default_rng(4)
     same = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
     assert np.array_equal(_resize(pt, same), same)                  # already 512 x 512: untouched (loader.cpp:222)
@@ -293,17 +294,22 @@ def test_resize_to_512(pt, ol):
     up = _resize(pt, ramp).astype(np.float64)
     want = np.stack([np.clip((np.arange(512) + 0.5) / 2 - 0.5, 0, 255)] * 512, 0)
     assert np.abs(up[..., 0] - want)[:, 4:-4].max() <= 1.0           # a linear ramp is reproduced by Catmull-Rom
-    # against the reference's own stb_image_resize where it exists (build container): the filters are the same, the
-    # accumulation order is not pinned -> a small bound, not equality
+    # byte for byte what the reference's own stb_image_resize build makes of the seeded images of
+    # tests/golden/make_golden_resize.py (enlarging, shrinking, mixed, one axis already 512, 1 x 1 ...): CRC of the whole
+    # output + every 16th pixel from tests/golden/ref_resize.npz, and the full image live where that build exists
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_golden_resize as mg
+    G = golden("ref_resize.npz")
     R = ol.load_ref()
-    if R is not None and hasattr(R, "ref_stbir_resize_512"):
-        for shape in ((1024, 1024), (256, 256), (300, 700), (64, 64)):
-            src = np.clip(rng.normal(128, 60, shape + (3,)), 0, 255).astype(np.uint8)
-            src = (src.astype(np.float64) * 0.5 + np.roll(src, 3, 0) * 0.25 + np.roll(src, 5, 1) * 0.25).astype(np.uint8)
+    for i, shape in enumerate(mg.SHAPES):
+        src = mg.resize_case(i)
+        got = _resize(pt, src)
+        assert np.array_equal(got[::16, ::16], G[f"sub_{i}"]), shape
+        assert (zlib.crc32(got.tobytes()) & 0xffffffff) == int(G[f"crc_{i}"]), shape
+        if R is not None and hasattr(R, "ref_stbir_resize_512"):
             ref = np.zeros((512, 512, 3), np.uint8)
             assert R.ref_stbir_resize_512(ctypes.c_void_p(src.ctypes.data), src.shape[1], src.shape[0], ctypes.c_void_p(ref.ctypes.data)) == 1
-            diff = np.abs(_resize(pt, src).astype(int) - ref.astype(int))
-            assert diff.max() <= 2 and (diff > 0).mean() < 0.05, (shape, diff.max(), (diff > 0).mean())
+            assert np.array_equal(got, ref), shape
 
 
 def test_textured_glb_fills_the_layer_array(pt, tmp_path):
