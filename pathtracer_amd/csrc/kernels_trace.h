@@ -123,6 +123,7 @@ struct DevScene {
 	const char *tblob;
 	uint32_t n_records;    // inner nodes; 0 = nothing to traverse (a root that is a leaf)
 	uint32_t tblob_bytes;
+	uint32_t short_rcp;    // 1: every |det| the triangle test can see is below 2^126, where v_rcp_f32 + one Newton step IS 1/det (see k_trace)
 	const float4 *tris;    // triangle i at tris[4*i] (shading)
 	const float4 *mats;    // material i at mats[3*i]
 	const float4 *spheres; // sphere i at spheres[2*i]
@@ -507,7 +508,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					const v3 e2 = V(q2.x, q2.y, q2.z);
 					const v3 pv = cross(rd, e2);
 					const float det = dot(e1, pv);
-					const float inv_det = 1.0f / det;
+					// 1/det.  v_rcp_f32 + one FMA Newton step (3 instructions for the 12 of the correctly rounded division) returns
+					// the SAME bits as the IEEE division for every normal |x| < 2^126 -- all 4.26e9 of them checked
+					// (tools/verify_rcp.hip, profiles/r01g_verify_rcp.txt); a smaller |det| is rejected below whatever its
+					// reciprocal, and pt_upload_scene sets short_rcp only when no triangle's edges can produce a larger one.
+					float inv_det;
+					if (a.sc.short_rcp) {
+						const float r = __builtin_amdgcn_rcpf(det);
+						inv_det = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
+					} else inv_det = 1.0f / det;
 					const v3 tv = ro - v0;
 					const float u = dot(tv, pv) * inv_det;
 					if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {

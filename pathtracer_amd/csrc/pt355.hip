@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -436,8 +437,11 @@ int pt_destroy(pt_ctx *c)
 // index) in the order the records reference them: the triangles of a left leaf, then those of its right sibling.
 // Also proves what the kernel relies on: every link lands inside the blob and every node has at most one parent
 // (so the walk from the root is a tree walk and ends).
-static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<uint32_t> &blob, uint32_t *n_records)
+static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<uint32_t> &blob, uint32_t *n_records, bool *short_rcp)
 {
+	// |det| = |e1 . (rd x e2)| <= 2 |rd|_inf |e1|_1 |e2|_1 with |rd|_inf <= 1 (a normalised direction rounded to fp16); the
+	// factor 16 leaves room for the roundings.  Stays below 2^126 for anything but absurd coordinates.
+	double det_bound = 0.0;
 	const float *nd = (const float *) s->nodes;
 	const float *tr = (const float *) s->tris;
 	const uint32_t n = s->n_nodes;
@@ -516,6 +520,12 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 					const float e1 = src[4 + a] - v0[a], e2 = src[8 + a] - v0[a];
 					d[a] = f2u(v0[a]); d[4 + a] = f2u(e1); d[8 + a] = f2u(e2);
 				}
+				{
+					double l1[2] = {0.0, 0.0};
+					for (int a = 0; a < 3; a++) { l1[0] += fabs((double) (src[4 + a] - v0[a])); l1[1] += fabs((double) (src[8 + a] - v0[a])); }
+					const double b = 16.0 * l1[0] * l1[1];
+					if (!(b <= det_bound)) det_bound = b; // NaN / inf make the bound NaN / inf: the short form is then off
+				}
 				d[3] = (uint32_t) t;
 			}
 			tt.insert(tt.end(), d, d + 16);
@@ -550,6 +560,7 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 	}
 	blob.insert(blob.end(), tt.begin(), tt.end());
 	*n_records = n_inner;
+	*short_rcp = det_bound < 0x1p126;
 	return PT_OK;
 }
 
@@ -599,12 +610,14 @@ int pt_upload_scene(pt_ctx *c, const pt_scene_desc *s)
 	int rc;
 	std::vector<uint32_t> blob;
 	uint32_t n_records = 0;
-	if ((rc = build_traversal_blob(c, s, blob, &n_records))) return rc;
+	bool short_rcp = false;
+	if ((rc = build_traversal_blob(c, s, blob, &n_records, &short_rcp))) return rc;
 	char *tb = nullptr;
 	if ((rc = upload(c, blob.data(), blob.size() * 4, &tb))) return rc; // hipMalloc is 256-B aligned: records sit on 64-B lines
 	d.tblob = tb;
 	d.n_records = n_records;
 	d.tblob_bytes = (uint32_t) (blob.size() * 4);
+	d.short_rcp = short_rcp && !getenv("PT355_IEEE_RCP") ? 1u : 0u;
 	char *tmp = nullptr;
 	if ((rc = upload(c, s->tris, (size_t) s->n_tris * 64, &tmp))) return rc;
 	d.tris = (const float4 *) tmp;

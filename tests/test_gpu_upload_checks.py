@@ -119,6 +119,43 @@ def test_non_contiguous_sibling_leaves(pt, ol):
     assert np.array_equal(uv.view(np.uint32), ouv.view(np.uint32))
 
 
+def test_astronomic_coordinates_take_the_ieee_division(pt, ol):
+    """The triangle test's 1/det is v_rcp_f32 + one Newton step only when pt_upload_scene has proved |det| < 2^126 for every
+    triangle (where that form equals the IEEE division bit for bit; above it the short form is wrong for EVERY input).
+    Four triangles with edges of ~2^63 in front of the origin give determinants of 2^126 ... 2^127.6 and perfectly ordinary
+    hits at t = 1 ... 4: the proof fails, the kernel must divide, and the hits must equal the oracle's."""
+    base = pt.Scene.soup(64, seed=9).arrays()
+    big = 2.0 ** 62
+    tris = base["tris"][:4].copy()
+    tf = tris.view(np.float32)
+    for i, (s, z) in enumerate(((1.5, -1.0), (1.25, -2.0), (1.75, -3.0), (1.0, -4.0))):
+        tf[i, 0:3] = (-s * big, -s * big, z)
+        tf[i, 4:7] = (s * big, -s * big, z)
+        tf[i, 8:11] = (0.0, s * big, z)
+    nodes = np.zeros((3, 8), np.float32)
+    nodes[0, 0:3], nodes[0, 4:7], nodes[0, 3] = (-2 * big, -2 * big, -4.0), (2 * big, 2 * big, -1.0), 1.0
+    nodes[1, 0:3], nodes[1, 4:7], nodes[1, 3], nodes[1, 7] = (-2 * big, -2 * big, -2.0), (2 * big, 2 * big, -1.0), 0.0, 2.0
+    nodes[2, 0:3], nodes[2, 4:7], nodes[2, 3], nodes[2, 7] = (-2 * big, -2 * big, -4.0), (2 * big, 2 * big, -3.0), 2.0, 2.0
+    d = _desc_from(pt, base, tris=tris, nodes=nodes.view(np.uint32), light_tris=np.zeros(0, np.uint32), spheres=np.zeros((0, 8), np.uint32),
+                   light_spheres=np.zeros(0, np.uint32))
+    rng = np.random.default_rng(12)
+    n = 20000
+    ro = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), rng.uniform(-3.5, 5.0, n)], 1).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd[:, 2] = -np.abs(rd[:, 2]) - 0.2
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    c = pt.PathTracer(8, 8)
+    try:
+        c.upload_scene(d)
+        prim, th, kind, uv = c.trace_closest(ro, rd)
+    finally:
+        c.close()
+    oprim, oth, okind, ouv = ol.trace_closest(ol.scene_from_desc(d), ro, rd)
+    assert (okind == 1).mean() > 0.5 and len(set(oprim[okind == 1].tolist())) == 4
+    assert np.array_equal(kind, okind) and np.array_equal(prim, oprim) and np.array_equal(th, oth)
+    assert np.array_equal(uv.view(np.uint32), ouv.view(np.uint32))
+
+
 def test_create_says_how_much_memory_it_needs(pt):
     """An image whose queues cannot fit (16384 x 16384 = the largest size pt_create accepts, 4 pipelines) is refused with the
     figures, before any allocation fails half way; the same image with a one-frame batch and one pipeline is accepted
