@@ -45,6 +45,15 @@ PT_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PT_DEV v3 cross(v3 a, v3 b) { return V(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 PT_DEV v3 normalize(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot(a, a)); return a * inv; }
 PT_DEV v3 q16(v3 a) { return V(q16(a.x), q16(a.y), q16(a.z)); }
+// 1.0f / x for an x that came out of q16(): v_rcp_f32 + one Newton step is bit-equal to the IEEE division for every normal
+// |x| < 2^126 (tools/verify_rcp.hip: all of them checked), which covers every finite non-zero fp16 value (2^-24 ... 65504);
+// v_div_fixup_f32 supplies the IEEE answers for the rest of fp16 (+-0 -> +-inf, +-inf -> +-0, NaN).  5 instructions for the
+// 12 of the general division; test_gpu_math.py::test_rcp_of_fp16_values checks all 65,536 inputs against the division.
+PT_DEV float rcp_of_q16(float x)
+{
+	const float r = __builtin_amdgcn_rcpf(x);
+	return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r), x, 1.0f);
+}
 
 struct m3 { v3 r0, r1, r2; }; // rows
 PT_DEV v3 mul(const m3 &m, v3 v) { return V(dot(m.r0, v), dot(m.r1, v), dot(m.r2, v)); }

@@ -876,6 +876,7 @@ __global__ void k_debug_eval(int op, const float *a, const float *b, uint32_t n,
 		}
 		break;
 	}
+	case 100: r = rcp_of_q16(x); break; // k_trace's reciprocal of a direction component (device only: no oracle counterpart)
 	default: break;
 	}
 	out[i] = r;

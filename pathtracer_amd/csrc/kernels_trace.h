@@ -224,8 +224,9 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 PT_DEV float shadow_kill_component(float y, float ro, float rd)
 {
 	if (!(rd > 0.0f)) return -__builtin_inff();
-	float cand = (float) to_h16(((y - ro) - PT_FLOAT_COMPARE) / rd);
-	// the division is only a guess: step down in fp16 until the shading kernel's own expression confirms it
+	float cand = (float) to_h16(((y - ro) - PT_FLOAT_COMPARE) * __builtin_amdgcn_rcpf(rd));
+	// the quotient is only a guess (hence the 1-ulp hardware reciprocal): step down in fp16 until the shading kernel's own
+	// expression confirms it
 	for (int i = 0; i < 3; i++) {
 		if ((y - (ro + rd * cand)) >= PT_FLOAT_COMPARE) return cand;
 		cand = (float) h_from_bits(h_bits(to_h16(cand)) - (cand > 0.0f ? 1u : 0u));
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						// fc:437 -- traversal sees the ray rounded to fp16 and widened again
 						ro = q16(fro);
 						rd = q16(frd);
-						inv = V(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z); // fc:347
+						inv = V(rcp_of_q16(rd.x), rcp_of_q16(rd.y), rcp_of_q16(rd.z)); // fc:347: 1.0 / rd, bit for bit
 						tmax = PT_TMAX;
 						sp = 0; tri = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;

@@ -54,6 +54,16 @@ def test_unary_ops(ctx, ol, op, lo, hi):
     assert _same(ctx.debug_eval(ol.OP[op], a), ol.math(op, a))
 
 
+def test_rcp_of_fp16_values(ctx, ol):
+    """k_trace computes 1/rd for directions that went through fp16 with a 5-instruction reciprocal: it must be the IEEE
+    quotient for EVERY fp16 value (zeros, denormals, infinities, NaNs included) -- compared with the device's own
+    correctly rounded division (which test_binary_ops pins to the oracle's) and with the oracle directly."""
+    h = np.arange(65536, dtype=np.uint16).view(np.float16).astype(np.float32)
+    got = ctx.debug_eval(100, h)
+    assert _same(got, ctx.debug_eval(ol.OP["DIV"], np.ones_like(h), h))
+    assert _same(got, ol.math("DIV", np.ones_like(h), h))
+
+
 def test_rand_clamp(ctx, ol):
     st = np.random.default_rng(5).integers(0, 2**32, 300000, dtype=np.uint64).astype(np.uint32)
     st[:4] = [0, 1, 0xffffffff, 0x80000000]
