@@ -1,6 +1,6 @@
 /* ptbench -- minimal native driver of libpt355.so for profiling runs (rocprofv3 wants the program itself after
  * "--", and a PMC pass should not pay a Python start-up).  Renders the bench.py workload: bunny-class scene,
- * 1920x1080, MIS, 5 bounces.   usage: ptbench [frames] [width] [height] [scene: 0 bunny ON, 1 bunny GGX, 2 cornell] [flags]
+ * 1920x1080, MIS, 5 bounces.   usage: ptbench [frames] [width] [height] [scene: 0 bunny ON, 1 bunny GGX, 2 cornell, 3 atrium (untextured)] [flags]
  * The warm-up is one full batch (pt_get_info: frames per launch set), so that every launch a profiler sees has the size
  * of the timed ones (give a multiple of the batch as `frames`) and its per-kernel averages are those of the timed region. */
 #include <stdio.h>
@@ -23,7 +23,8 @@ int main(int argc, char **argv)
 	const int which = argc > 4 ? atoi(argv[4]) : 0;
 	const uint32_t flags = argc > 5 ? (uint32_t) strtoul(argv[5], 0, 0) : 0;
 	pth_scene *s = pth_scene_create();
-	int rc = which == 2 ? pth_scene_make_cornell(s, 0)
+	int rc = which == 3 ? pth_scene_make_atrium(s, 4, 1)
+	       : which == 2 ? pth_scene_make_cornell(s, 0)
 	       : which == 1 ? pth_scene_make_bunny(s, 59, 69451, 1, PTH_MAT_SPECULAR_METAL, 0.2f, 1)
 	                    : pth_scene_make_bunny(s, 59, 69451, 1, PTH_MAT_OREN_NAYAR, 0.175f, 0);
 	if (rc) { fprintf(stderr, "scene generator failed: %d\n", rc); return 1; }
