@@ -39,6 +39,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # k_trace's cache-miss read requests per global record fetch on the bunny workload (profiles/r02d_pmc_traffic.json, k_trace_all);
 # used for the gather ceiling only when the workload being benched has no PMC passes of its own
 DEFAULT_MISS_L1, DEFAULT_MISS_L2 = 0.57, 0.11
+BVH_NAMES = {"reference": "Sweep-SAH", "lbvh": "GPU-built LBVH", "ploc": "GPU-built PLOC"}
 
 
 def make_scene(pt, name):
@@ -121,6 +122,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default="bunny")
     ap.add_argument("--bounces", type=int, default=5)
+    ap.add_argument("--bvh", choices=["reference", "lbvh", "ploc"], default="reference",
+                    help="reference = the reference's own Sweep-SAH builder (what its renders use; the default and the parity contract); "
+                         "lbvh / ploc = the GPU builders of pt_build_bvh_device (max_leaf 2)")
     ap.add_argument("--partition", choices=["samples", "tiles"], default="samples",
                     help="N > 1: samples = frames dealt round-robin (weak scaling), tiles = 8x8 screen tiles (strong scaling, bit-identical)")
     ap.add_argument("--max-batch", type=int, default=0, help="frames traced per launch set (0 = library default)")
@@ -165,6 +169,11 @@ def main():
     scene = make_scene(pt, args.scene)  # generator + the reference's single-threaded Sweep-SAH build (CalculateBVH)
     t_scene = time.perf_counter() - t_scene
     flags = pt.PT_FLAG_TRACE_DEAD_PATHS if args.trace_dead_paths else 0
+    t_gpu_bvh_ms = None
+    if args.bvh != "reference":
+        bctx = pt.PathTracer(8, 8, device=local_rank)
+        t_gpu_bvh_ms = bctx.finalize_scene_device(scene, 2, ploc=args.bvh == "ploc")
+        bctx.close()
     if tiles:
         ctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, partition=pt.PT_PARTITION_TILES, rank=rank, world=world,
                             max_batch=args.max_batch)
@@ -313,7 +322,7 @@ def main():
     avg_launch_ms = cnt["ms_trace"] / launches  # HIP events recorded around every k_trace launch on the context's stream
     rays_per_launch = rays / launches
     sec = avg_launch_ms * 1e-3
-    workload_key = f"{args.scene}-{args.width}x{args.height}-b{args.bounces}"
+    workload_key = f"{args.scene}-{args.width}x{args.height}-b{args.bounces}" + ("" if args.bvh == "reference" else f"-{args.bvh}")
     pmc = pmc_profile(workload_key)
     kern = (pmc or {}).get("kernels", {})
     pk = kern.get("k_trace_all") or kern.get("k_trace", {})  # all trace launches of a batch, like the HIP-event average here
@@ -403,7 +412,7 @@ def main():
         "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "strong" if tiles else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.scene}: {d.n_tris} triangles, Sweep-SAH BVH {d.n_nodes} nodes, {args.width}x{args.height}, "
+        "config": {"workload": f"{args.scene}: {d.n_tris} triangles, {BVH_NAMES[args.bvh]} BVH {d.n_nodes} nodes, {args.width}x{args.height}, "
                                f"{K} spp per GPU, {args.bounces} bounces, MIS (BSDF + NEE), shadow rays closest-hit "
                                f"(reference semantics), {ctx.max_batch} frames per launch set",
                    "scene_hash": f"{scene.hash():016x}",
@@ -413,7 +422,8 @@ def main():
         "spp_per_s": round(spp_total / dt, 3), "mpaths_per_s": round(paths_total / dt / 1e6, 2),
         "rays": {"primary": cnt["rays_primary"], "shadow": cnt["rays_shadow"], "bounce": cnt["rays_bounce"], "scope": "rank0" if world > 1 else "all"},
         "stack_spills": cnt["stack_spills"], "roofline": roofline, "cpu_baseline": cpu,
-        "setup": {"scene_generation_and_cpu_bvh_build_s": round(t_scene, 3), "upload_incl_traversal_blob_ms": round(t_upload * 1e3, 2)},
+        "setup": {"scene_generation_and_cpu_bvh_build_s": round(t_scene, 3), "upload_incl_traversal_blob_ms": round(t_upload * 1e3, 2),
+                  "gpu_bvh_build_ms": round(t_gpu_bvh_ms, 3) if t_gpu_bvh_ms is not None else None},
     }
     if check is not None:
         out["check"] = check

@@ -217,13 +217,16 @@ int pt_group_get_counters(pt_group *g, pt_counters *out); /* sums over the membe
 int pt_debug_eval(pt_ctx *ctx, int op, const float *a, const float *b, uint32_t n, float *out);
 
 /* ---- BVH build on the GPU.  The reference builds on one CPU thread (CalculateBVH, src/scene/bvh.cpp:31-75,
- * rebuilt bit for bit as pth_build_bvh); this is the same step for scenes where that build dominates the set-up: a
- * linear BVH (Morton order, radix tree, bottom-up bounds; subtrees of <= max_leaf triangles become leaves, max_leaf
- * 1..16, 0 = 2) built on ctx's device and returned in the reference's own layout -- same arguments and output
- * contract as pth_build_bvh: tris = n packed 64-byte triangles in any order, nodes_out = room for 2n+1 32-byte nodes,
- * sorted_out = n triangles in leaf order.  The tree differs from the Sweep-SAH tree (the bit-exactness contract covers
- * the CPU builder); it is a valid input of pt_upload_scene, the oracle and the reference's shader.  build_ms
- * (optional) receives the device time of the build proper. */
+ * rebuilt bit for bit as pth_build_bvh); this is the same step for scenes where that build dominates the set-up, on ctx's
+ * device, returned in the reference's own layout -- same arguments and output contract as pth_build_bvh: tris = n packed
+ * 64-byte triangles in any order, nodes_out = room for 2n+1 32-byte nodes, sorted_out = n triangles in leaf order.
+ * Two builders: a linear BVH (Morton order, radix tree, bottom-up bounds: the fastest) and, with PT_BVH_PLOC or-ed into
+ * max_leaf, parallel locally-ordered clustering over the same Morton order (bottom-up merging by the area of the merged
+ * box: a better tree for a longer build).  Subtrees of <= max_leaf triangles become leaves (max_leaf 1..16, 0 = 2).
+ * Either tree differs from the Sweep-SAH tree (the bit-exactness contract covers the CPU builder); it is a valid input
+ * of pt_upload_scene, the oracle and the reference's shader.  build_ms (optional) receives the device time of the
+ * build proper. */
+#define PT_BVH_PLOC 0x100u
 int pt_build_bvh_device(pt_ctx *ctx, const void *tris, uint32_t n, uint32_t max_leaf, void *nodes_out, uint32_t *n_nodes_out,
                         void *sorted_out, float *build_ms);
 /* pth_scene_finalize (pt355_host.h) with that builder in place of CalculateBVH */

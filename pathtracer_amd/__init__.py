@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libpt355.so")
 PT_FLAG_SHADOW_ANYHIT = 1
 PT_FLAG_TRACE_DEAD_PATHS = 2
 PT_FLAG_COUNT_TRAVERSAL = 4
+PT_BVH_PLOC = 0x100  # or-ed into max_leaf of the GPU BVH builders: clustering (PLOC) instead of the radix tree
 PT_FLAG_SHADOW_FULL_TRAVERSAL = 8
 PT_ESTIMATOR_MIS, PT_ESTIMATOR_NEE, PT_ESTIMATOR_BRDF = 0, 1, 2
 PT_PARTITION_TILES = 0
@@ -488,21 +489,22 @@ class PathTracer:
     def unpack_from(self, src_ptr: int, from_rank: int, world: int):
         self._check(lib().pt_unpack_from(self._h, c_void_p(src_ptr), from_rank, world), "pt_unpack_from")
 
-    def build_bvh_device(self, tris, max_leaf: int = 4):
-        """GPU LBVH over n packed 64-byte triangles (u32 [n,16]); returns (nodes u32 [m,8], sorted tris u32 [n,16], build ms)."""
+    def build_bvh_device(self, tris, max_leaf: int = 4, ploc: bool = False):
+        """GPU BVH (LBVH, or PLOC with ploc=True) over n packed 64-byte triangles (u32 [n,16]); returns (nodes u32 [m,8],
+        sorted tris u32 [n,16], build ms)."""
         tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 16)
         n = tris.shape[0]
         nodes = np.zeros((2 * n + 1, 8), np.uint32)
         out = np.zeros_like(tris)
         nn, ms = c_uint32(), c_float()
-        self._check(lib().pt_build_bvh_device(self._h, _ptr(tris), n, max_leaf, _ptr(nodes), byref(nn), _ptr(out), byref(ms)),
-                    "pt_build_bvh_device")
+        self._check(lib().pt_build_bvh_device(self._h, _ptr(tris), n, max_leaf | (PT_BVH_PLOC if ploc else 0), _ptr(nodes), byref(nn), _ptr(out),
+                                              byref(ms)), "pt_build_bvh_device")
         return nodes[: nn.value].copy(), out, ms.value
 
-    def finalize_scene_device(self, scene: "Scene", max_leaf: int = 4) -> float:
+    def finalize_scene_device(self, scene: "Scene", max_leaf: int = 4, ploc: bool = False) -> float:
         """Re-finalizes `scene` with the GPU builder in place of CalculateBVH; returns the build's device ms."""
         ms = c_float()
-        self._check(lib().pt_scene_finalize_device(self._h, scene._h, max_leaf, byref(ms)), "pt_scene_finalize_device")
+        self._check(lib().pt_scene_finalize_device(self._h, scene._h, max_leaf | (PT_BVH_PLOC if ploc else 0), byref(ms)), "pt_scene_finalize_device")
         return ms.value
 
     def debug_read_queue(self, queue: int, field: int) -> np.ndarray:

@@ -1051,7 +1051,9 @@ int pt_build_bvh_device(pt_ctx *c, const void *tris, uint32_t n, uint32_t max_le
 	Range range("pt355 build_bvh_device");
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
 	char err[256] = "";
-	const int rc = ptb_build_lbvh(c->stream, tris, n, max_leaf ? max_leaf : 2u, nodes_out, n_nodes_out, sorted_out, build_ms, err, sizeof err);
+	const int method = (max_leaf & PT_BVH_PLOC) ? 1 : 0;
+	max_leaf &= ~(uint32_t) PT_BVH_PLOC;
+	const int rc = ptb_build_bvh(c->stream, method, tris, n, max_leaf ? max_leaf : 2u, nodes_out, n_nodes_out, sorted_out, build_ms, err, sizeof err);
 	if (rc) return fail(c, rc == 1 ? PT_EINVAL : PT_EHIP, "%s", err);
 	return PT_OK;
 }

@@ -51,13 +51,17 @@ def _check_tree(nodes_u32, tris_u32, max_leaf):
     return max_depth
 
 
+PLOC = pytest.mark.parametrize("ploc", [False, True], ids=["lbvh", "ploc"])
+
+
+@PLOC
 @pytest.mark.parametrize("max_leaf", [1, 4, 16])
-def test_tree_is_valid_and_a_permutation(pt, max_leaf):
+def test_tree_is_valid_and_a_permutation(pt, max_leaf, ploc):
     sc = pt.Scene.soup(20000, seed=11, size=0.3)
     src = sc.arrays()["tris"]
     c = pt.PathTracer(8, 8)
     try:
-        nodes, sorted_tris, ms = c.build_bvh_device(src, max_leaf)
+        nodes, sorted_tris, ms = c.build_bvh_device(src, max_leaf, ploc=ploc)
     finally:
         c.close()
     assert ms > 0.0
@@ -67,7 +71,8 @@ def test_tree_is_valid_and_a_permutation(pt, max_leaf):
     _check_tree(nodes, sorted_tris, max_leaf)
 
 
-def test_duplicates_and_flat_scenes(pt):
+@PLOC
+def test_duplicates_and_flat_scenes(pt, ploc):
     """Coincident centroids (identical Morton codes) and a scene with zero extent on one axis."""
     sc = pt.Scene.soup(64, seed=3, size=0.3)
     t = sc.arrays()["tris"]
@@ -77,7 +82,7 @@ def test_duplicates_and_flat_scenes(pt):
     c = pt.PathTracer(8, 8)
     try:
         for src in (dup, flat.view(np.uint32)):
-            nodes, st, _ = c.build_bvh_device(src, 2)
+            nodes, st, _ = c.build_bvh_device(src, 2, ploc=ploc)
             depth = _check_tree(nodes, st, 800)           # duplicates cannot be split by position: leaves may not shrink...
             assert depth <= 64
     finally:
@@ -96,14 +101,15 @@ def test_argument_checks(pt):
         c.close()
 
 
+@PLOC
 @pytest.mark.parametrize("maker", ["soup", "bunny"])
-def test_closest_hits_through_the_gpu_tree(pt, ol, maker):
+def test_closest_hits_through_the_gpu_tree(pt, ol, maker, ploc):
     sah = pt.Scene.soup(20000, seed=11, size=0.3) if maker == "soup" else pt.Scene.bunny(spheres=True)
     lbvh = pt.Scene.soup(20000, seed=11, size=0.3) if maker == "soup" else pt.Scene.bunny(spheres=True)
     ro, rd = _rays(200000, 5)
     c = pt.PathTracer(8, 8)
     try:
-        c.finalize_scene_device(lbvh, 4)
+        c.finalize_scene_device(lbvh, 4, ploc=ploc)
         assert lbvh.hash() != sah.hash()
         c.upload_scene(lbvh)
         prim, th, kind, uv = c.trace_closest(ro, rd)
@@ -131,11 +137,12 @@ def test_closest_hits_through_the_gpu_tree(pt, ol, maker):
     assert same_tri > 0.995, same_tri
 
 
-def test_frames_through_the_gpu_tree_match_the_oracle(pt, ol):
+@PLOC
+def test_frames_through_the_gpu_tree_match_the_oracle(pt, ol, ploc):
     sc = pt.Scene.bunny(freq=12, target_tris=0, seed=2)
     c = pt.PathTracer(64, 64)
     try:
-        c.finalize_scene_device(sc, 4)
+        c.finalize_scene_device(sc, 4, ploc=ploc)
         c.upload_scene(sc)
         c.set_camera(pt.default_camera())
         seeds = pt.frame_seeds(0, 3)
@@ -148,7 +155,8 @@ def test_frames_through_the_gpu_tree_match_the_oracle(pt, ol):
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 
-def test_million_triangles_build_time(pt):
+@PLOC
+def test_million_triangles_build_time(pt, ploc):
     """C5-class set-up: 1 M triangles built on the device, uploaded and traced; prints the build time next to the CPU builder's."""
     import time
     rng = np.random.default_rng(9)
@@ -162,9 +170,9 @@ def test_million_triangles_build_time(pt):
     c = pt.PathTracer(8, 8)
     try:
         t0 = time.time()
-        nodes, st, ms = c.build_bvh_device(tris.view(np.uint32), 4)
+        nodes, st, ms = c.build_bvh_device(tris.view(np.uint32), 4, ploc=ploc)
         wall = time.time() - t0
     finally:
         c.close()
     depth = _check_tree(nodes, st, 4)
-    print(f"\n1M triangles: LBVH build {ms:.2f} ms on the device ({wall * 1e3:.0f} ms incl. PCIe both ways), {nodes.shape[0]} nodes, depth {depth}")
+    print(f"\n1M triangles: {'PLOC' if ploc else 'LBVH'} build {ms:.2f} ms on the device ({wall * 1e3:.0f} ms incl. PCIe both ways), {nodes.shape[0]} nodes, depth {depth}")

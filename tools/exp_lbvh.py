@@ -20,9 +20,11 @@ t0 = time.time(); sah = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, mater
 print(f"scene generation + CPU Sweep-SAH build: {t_cpu*1e3:.0f} ms")
 for fl in (0, 4):
     run(sah, "Sweep-SAH (reference builder)", fl)
-for ml in (1, 2, 4, 8):
-    lb = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
-    c = pt.PathTracer(8, 8); ms = c.finalize_scene_device(lb, ml); c.close()
-    print(f"LBVH max_leaf {ml}: build {ms:.2f} ms, {lb.arrays()['nodes'].shape[0]} nodes")
-    for fl in (0, 4):
-        run(lb, f"LBVH max_leaf {ml}", fl)
+for ploc in (False, True):
+    name = "PLOC" if ploc else "LBVH"
+    for ml in (1, 2, 4, 8):
+        lb = pt.Scene.bunny(freq=59, target_tris=69451, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
+        c = pt.PathTracer(8, 8); ms = c.finalize_scene_device(lb, ml, ploc=ploc); ms = c.finalize_scene_device(lb, ml, ploc=ploc); c.close()
+        print(f"{name} max_leaf {ml}: build {ms:.2f} ms, {lb.arrays()['nodes'].shape[0]} nodes")
+        for fl in (0, 4):
+            run(lb, f"{name} max_leaf {ml}", fl)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Trace throughput vs scene size (GPU box): the bench mesh at 70 k, 264 k, 1 M and 4 M triangles, 1080p MIS, Sweep-SAH
-tree from the CPU builder and LBVH from the GPU builder."""
+tree from the CPU builder, LBVH and PLOC trees from the GPU builders."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,3 +30,7 @@ for freq in (59, 115, 224, 450):
     t0 = time.time(); ms = c.finalize_scene_device(sc, 2); t_gpu = time.time() - t0
     c.close()
     run(sc, f"freq {freq}: LBVH ({ms:6.2f} ms dev, {t_gpu:4.1f} s)")
+    c = pt.PathTracer(8, 8)
+    t0 = time.time(); ms = c.finalize_scene_device(sc, 2, ploc=True); t_gpu = time.time() - t0
+    c.close()
+    run(sc, f"freq {freq}: PLOC ({ms:6.2f} ms dev, {t_gpu:4.1f} s)")
