@@ -214,7 +214,9 @@ __global__ void k_gather(const float4 *tris, const unsigned long long *keys, uin
 // and area-driven where the radix tree only looks at key bits: on the bench mesh its trees take a third fewer traversal
 // steps than the LBVH's and a tenth fewer than the reference's Sweep-SAH trees (profiles/r02f_lbvh_vs_ploc_vs_sah.txt).  The root is the last node made, so inner-node ids are
 // handed out downwards from n - 2 and the root is node 0, as the emit stage expects.
+#ifndef PLOC_RADIUS
 #define PLOC_RADIUS 16
+#endif
 
 __device__ inline float half_area_union(const Box &a, const Box &b)
 {
