@@ -65,8 +65,11 @@ while time.time() < t_end:
     cam = camera()
     gpu_tree = rng.random() < 0.25 and sc.desc().n_tris >= 2
     ploc = bool(rng.integers(0, 2))
-    c = pt.PathTracer(w, h, flags=pt.PT_FLAG_TRACE_DEAD_PATHS, max_batch=int(rng.choice([0, 1, 2])))
+    est, oflag = ([(pt.PT_ESTIMATOR_MIS, 0)] * 4 + [(pt.PT_ESTIMATOR_NEE, ol.FLAG_EST_NEE), (pt.PT_ESTIMATOR_BRDF, ol.FLAG_EST_BRDF)])[int(rng.integers(0, 6))]
+    gflags = pt.PT_FLAG_TRACE_DEAD_PATHS | (pt.PT_FLAG_SHADOW_FULL_TRAVERSAL if rng.random() < 0.3 else 0)
+    c = pt.PathTracer(w, h, flags=gflags, max_batch=int(rng.choice([0, 1, 2])), pipelines=int(rng.choice([1, 1, 2])))
     try:
+        c.set_estimator(est)
         if gpu_tree:
             c.finalize_scene_device(sc, int(rng.choice([1, 2, 4, 16])), ploc=ploc)
         c.upload_scene(sc, tex_rgb8=tex)
@@ -75,7 +78,7 @@ while time.time() < t_end:
         img, cnt = c.read_framebuffer(), c.counters()
     finally:
         c.close()
-    ref, ocnt = ol.render(ol.scene_from_desc(sc.desc(), tex_rgb8=tex), cam, w, h, seeds, first_frame=first, bounces=bounces, threads=16)
+    ref, ocnt = ol.render(ol.scene_from_desc(sc.desc(), tex_rgb8=tex), cam, w, h, seeds, first_frame=first, bounces=bounces, threads=16, flags=oflag)
     diff = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
     cdiff = [k for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce") if cnt[k] != ocnt[k]]
     n += 1
@@ -85,6 +88,6 @@ while time.time() < t_end:
         print(f"... {n} configurations ({lit} with a lit image, {rays / 1e6:.1f} M rays), {bad} mismatches, {t_end - time.time():.0f} s left", flush=True)
     if diff or cdiff:
         bad += 1
-        print(f"MISMATCH #{n}: {name} {w}x{h} frames {frames} first {first} bounces {bounces} gpu_tree {gpu_tree}/{ploc}: {diff} pixels, counters {cdiff}", flush=True)
+        print(f"MISMATCH #{n}: {name} {w}x{h} frames {frames} first {first} bounces {bounces} gpu_tree {gpu_tree}/{ploc} est {est} flags {gflags}: {diff} pixels, counters {cdiff}", flush=True)
 print(f"soak: {n} configurations ({lit} with a lit image, {rays / 1e6:.1f} M rays), {bad} mismatches, {budget:.0f} s budget")
 sys.exit(1 if bad else 0)
