@@ -8,9 +8,8 @@
 // bit-exactness contract covers the CPU builder; any valid tree yields the same closest hit up to ties of the
 // fp16-quantised t.
 //
-// Stages (all on `stream`): centroid bounds -> 64-bit keys (39-bit Morton code << 24 | triangle index: unique, so the
-// radix tree is at most 63 levels deep = inside the traversal stack; 13 bits per axis because a mesh usually fills a small
-// part of the scene's bounds -- at 10 bits most of the bench mesh's splits were decided by the index tie-break) -> hipcub radix sort -> hierarchy -> bottom-up
+// Stages (all on `stream`): centroid bounds -> 64-bit keys (39-bit extended Morton code << 24 | triangle index: unique,
+// so the radix tree is at most 63 levels deep = inside the traversal stack; see k_keys) -> hipcub radix sort -> hierarchy -> bottom-up
 // bounds (second arrival at a node merges its children) -> subtrees of <= max_leaf triangles collapse into leaves ->
 // prefix sum numbers the surviving inner nodes -> nodes and sorted triangles are written.
 #include <hip/hip_runtime.h>
@@ -18,6 +17,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "bvh_device.h"
@@ -74,21 +74,41 @@ __device__ inline unsigned long long spread13(uint32_t v)
 	return x;
 }
 
-// key = 39-bit Morton code of the centroid (13 bits per axis of the centroid bounds) << 24 | triangle index: 63 bits, unique
-__global__ void k_keys(const float4 *tris, uint32_t n, const int *cb, unsigned long long *keys)
+// key = 39-bit code << 24 | triangle index: 63 bits, unique.  The code is the Morton code of the centroid (13 bits per
+// axis of the centroid bounds), or, with `extended` (Vinkler et al. 2017), 10 bits per axis interleaved with 9 bits of the
+// triangle's box diagonal relative to the scene's: large triangles then sort apart from the small ones around them
+// instead of stretching the boxes of their Morton neighbours.
+__global__ void k_keys(const float4 *tris, uint32_t n, const int *cb, unsigned long long *keys, int extended)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
 	const Box b = tri_box(tris + 4u * (size_t) i);
-	uint32_t q[3];
+	float t[3], ext2 = 0.0f, d2 = 0.0f;
 	for (int k = 0; k < 3; k++) {
 		const float lo = unordered(cb[k]), hi = unordered(cb[3 + k]);
 		const float ext = hi - lo;
-		float t = ext > 0.0f ? (0.5f * (b.lo[k] + b.hi[k]) - lo) / ext : 0.0f;
-		t = fminf(fmaxf(t, 0.0f), 1.0f);
-		q[k] = (uint32_t) fminf(t * 8192.0f, 8191.0f);
+		t[k] = ext > 0.0f ? (0.5f * (b.lo[k] + b.hi[k]) - lo) / ext : 0.0f;
+		t[k] = fminf(fmaxf(t[k], 0.0f), 1.0f);
+		ext2 += ext * ext;
+		d2 += (b.hi[k] - b.lo[k]) * (b.hi[k] - b.lo[k]);
 	}
-	const unsigned long long m = spread13(q[0]) | (spread13(q[1]) << 1) | (spread13(q[2]) << 2);
+	unsigned long long m;
+	if (!extended) {
+		uint32_t q[3];
+		for (int k = 0; k < 3; k++) q[k] = (uint32_t) fminf(t[k] * 8192.0f, 8191.0f);
+		m = spread13(q[0]) | (spread13(q[1]) << 1) | (spread13(q[2]) << 2);
+	} else {
+		uint32_t q[4];
+		for (int k = 0; k < 3; k++) q[k] = (uint32_t) fminf(t[k] * 1024.0f, 1023.0f);
+		const float rel = ext2 > 0.0f ? sqrtf(d2 / ext2) : 0.0f; // centroid bounds are smaller than the scene: may exceed 1
+		q[3] = (uint32_t) fminf(fminf(rel, 1.0f) * 512.0f, 511.0f);
+		m = 0;
+		int out = 38;
+		for (int bit = 9; bit >= 0; bit--) { // x y z s | x y z s | ... | x y z
+			for (int k = 0; k < 3; k++) m |= (unsigned long long) ((q[k] >> bit) & 1u) << out--;
+			if (bit >= 1) m |= (unsigned long long) ((q[3] >> (bit - 1)) & 1u) << out--;
+		}
+	}
 	keys[i] = (m << 24) | i;
 }
 
@@ -379,7 +399,7 @@ int ptb_build_bvh(hipStream_t stream, int method, const void *tris_host, uint32_
 	B_TRY(hipMemsetAsync(d_arrived, 0, (size_t) ni * 4, stream));
 	const uint32_t blk = 256, gn = (n + blk - 1) / blk, gi = (ni + blk - 1) / blk;
 	hipLaunchKernelGGL(k_bounds, dim3(gn), dim3(blk), 0, stream, d_tris, n, d_cb);
-	hipLaunchKernelGGL(k_keys, dim3(gn), dim3(blk), 0, stream, d_tris, n, d_cb, d_keys);
+	hipLaunchKernelGGL(k_keys, dim3(gn), dim3(blk), 0, stream, d_tris, n, d_cb, d_keys, getenv("PT355_BVH_PLAIN_MORTON") ? 0 : 1);
 	{
 		size_t tmp_bytes = 0;
 		B_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_keys, d_keys2, (int) n, 0, 63, stream));
