@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_gather_coop(const uint4 *__restrict__ t
 // (Round 2's first version took the TCP miss share per ACCESS as the share of steps outside the hot set; a record fetch is
 // four accesses of which only the first can miss, so that understated the kernel's misses fourfold and overstated the
 // ceiling.  `ubench_gather tiers ...` under rocprofv3 --pmc shows the model reproducing the requested rates:
-// profiles/r02c_ubench_calibration.txt.)  Measurement infrastructure, not product code: nothing in libpt355.so calls it.
+// profiles/r02g_ubench_calibration.txt.)  Measurement infrastructure, not product code: nothing in libpt355.so calls it.
 #define PTU_HOT_REC 256u            /* 16 KB */
 #define PTU_L2_REC (2u << 20 >> 6)  /* 2 MB  */
 #define PTU_COLD_REC (64u << 20 >> 6) /* 64 MB */
