@@ -53,6 +53,9 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_TRACE_BLOCK 256
 #define PT_TRACE_MIN_WAVES 7
 #endif
+#ifndef PT_EXEC_LOOP
+#define PT_EXEC_LOOP 1 // the traversal loop as a divergent loop of the active lanes (a retiring lane breaks out) instead of a wave-uniform loop around if (active)
+#endif
 #define PT_SPILL_STACK (64 - PT_SHORT_STACK) // together 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_WAVES (PT_TRACE_BLOCK / 64)
 #define PT_TOP_RECORDS (PT_TOP_BYTES / 64)
@@ -460,8 +463,17 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
 			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form, and again
 			// 1.5-5 % slower at 4/8/16 lanes after the tree top moved to LDS -- DESIGN.md "What was tried".)
+#if PT_EXEC_LOOP
+			uint32_t my_iters = 0;
+			// leave for a refill once no more than this many lanes are still traversing (never, once the queue is dry); one scalar
+			// for the whole loop: `exhausted` cannot change inside it
+			const int live_min = __builtin_amdgcn_readfirstlane(exhausted ? -1 : 64 - (int) a.refill_threshold);
+			if (active) for (;;) {
+				if (COUNT) my_iters++;
+#else
 			if (COUNT) n_iters++;
 			if (active) {
+#endif
 				const bool tmode = tri < tri_end;
 				const uint32_t off = tmode ? tri : cur;
 				float4 q0, q1, q2, q3;
@@ -537,11 +549,24 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						}
 					}
 				} else node_step(q0, q1, q2, q3);
+#if PT_EXEC_LOOP
+				// a retiring lane leaves the loop (its exec bit drops until the others follow); the rest go round again unless
+				// enough of the wave has gone idle for a refill
+				if (tri >= tri_end && cur == PT_CUR_DONE) { retire(); break; }
+				if ((int) __popcll(__ballot(true)) <= live_min) break;
+			}
+			if (COUNT) {
+				for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(my_iters, o); my_iters = other > my_iters ? other : my_iters; }
+				n_iters += my_iters;
+			}
+			break;
+#else
 				if (tri >= tri_end && cur == PT_CUR_DONE) retire();
 			}
 			const unsigned long long act = __ballot(active);
 			if (act == 0ull) break;
 			if (!exhausted && (64u - (uint32_t) __popcll(act)) >= a.refill_threshold) break;
+#endif
 		}
 	}
 

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pathtracer_amd as pt
 
-for freq in (21, 30, 36, 42, 48, 53, 59, 70, 84):
+for freq in [int(x) for x in sys.argv[1:]] or (21, 30, 36, 42, 48, 53, 59, 70, 84):
     sc = pt.Scene.bunny(freq=freq, target_tris=0, seed=1, material=pt.MAT_OREN_NAYAR, roughness=0.175)
     res = []
     for flags in (0, pt.PT_FLAG_COUNT_TRAVERSAL):
