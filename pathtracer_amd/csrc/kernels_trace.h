@@ -45,7 +45,7 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_SHORT_STACK 12
 #endif
 #ifndef PT_TRACE_BLOCK
-#define PT_TRACE_BLOCK 1024 // 16 waves share one copy of the tree top: 16 * 3 KB of stacks + 16 KB = 64 KB, two blocks per CU
+#define PT_TRACE_BLOCK 1024 // 16 waves share one copy of the tree top: 16 * 3.25 KB of stacks + 16 KB = 68 KB, two blocks per CU
 #endif
 #define PT_TRACE_MIN_WAVES 8 // two such blocks per CU need 8 waves per SIMD: at most 64 VGPRs
 #else
@@ -126,7 +126,7 @@ struct DevScene {
 	const char *tblob;
 	uint32_t n_records;    // inner nodes; 0 = nothing to traverse (a root that is a leaf)
 	uint32_t tblob_bytes;
-	uint32_t short_rcp;    // 1: every |det| the triangle test can see is below 2^126, where v_rcp_f32 + one Newton step IS 1/det (see k_trace)
+	uint32_t short_rcp;    // 1: every |det| the triangle test can see is below 2^126, where v_rcp_f32 + one Newton step IS 1/det: the host launches k_trace<.., IEEE_RCP = false>
 	const float4 *tris;    // triangle i at tris[4*i] (shading)
 	const float4 *mats;    // material i at mats[3*i]
 	const float4 *spheres; // sphere i at spheres[2*i]
@@ -251,12 +251,15 @@ PT_DEV float shadow_kill_component(float y, float ro, float rd)
 // descend/push/pop decision never depended on them (the stack holds record offsets only).
 // cur, tri, tri_end and the stack entries are byte offsets into the traversal blob: the address of either mode is
 // one select away, and no index is converted or range-checked here (pt_upload_scene proved every link).
-template <bool COUNT, bool GEN>
+template <bool COUNT, bool GEN, bool IEEE_RCP>
 __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(TraceArgs a)
 {
-	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK][64];
+	// level 0 of every lane's stack holds PT_CUR_DONE for good and sp starts at 1: popping the last entry needs no test for an
+	// empty stack, the lane just reads "done"
+	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK + 1][64];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *const lds = &s_stack[wave][0][lane];
+	lds[0] = PT_CUR_DONE;
 	uint32_t *const spill = a.spill + ((size_t) (blockIdx.x * PT_TRACE_WAVES + wave) * PT_SPILL_STACK) * 64 + lane;
 
 	if (blockIdx.x == 0 && threadIdx.x < PT_SHARDS && a.zero_on_entry) a.zero_on_entry[threadIdx.x * PT_SHARD_STRIDE] = 0;
@@ -321,17 +324,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 		const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
 		cur = both ? nearer : (go_l ? c_l : c_r);
 		if (both) {
-			if (__builtin_expect(sp < PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
-			else { spill[(sp - PT_SHORT_STACK) * 64u] = farther; n_spills++; } // sp < 64: pt_upload_scene bounds the depth
+			if (__builtin_expect(sp <= PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
+			else { spill[(sp - (PT_SHORT_STACK + 1u)) * 64u] = farther; n_spills++; } // sp <= 64: pt_upload_scene bounds the depth
 			sp++;
 		}
 		if (!any) {
-			cur = PT_CUR_DONE;
-			if (sp != 0u) {
-				sp--;
-				cur = lds[(sp < PT_SHORT_STACK ? sp : 0u) * 64u];
-				if (__builtin_expect(sp >= PT_SHORT_STACK, 0)) cur = spill[(sp - PT_SHORT_STACK) * 64u]; // rare: keeps the common pop a plain ds_read
-			}
+			// sp >= 1 here: a lane that has popped the sentinel of level 0 retires in the same iteration
+			sp--;
+			cur = lds[(sp < PT_SHORT_STACK ? sp : PT_SHORT_STACK) * 64u];
+			if (__builtin_expect(sp > PT_SHORT_STACK, 0)) cur = spill[(sp - (PT_SHORT_STACK + 1u)) * 64u]; // rare: keeps the common pop a plain ds_read
 		}
 	};
 	// Retire the lane's ray: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax).
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						rd = q16(frd);
 						inv = V(rcp_of_q16(rd.x), rcp_of_q16(rd.y), rcp_of_q16(rd.z)); // fc:347: 1.0 / rd, bit for bit
 						tmax = PT_TMAX;
-						sp = 0; tri = 0; tri_end = 0;
+						sp = 1; tri = 0; tri_end = 0;
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
 						if (occluded_now) {
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					// (tools/verify_rcp.hip, profiles/r01g_verify_rcp.txt); a smaller |det| is rejected below whatever its
 					// reciprocal, and pt_upload_scene sets short_rcp only when no triangle's edges can produce a larger one.
 					float inv_det;
-					if (a.sc.short_rcp) {
+					if (!IEEE_RCP) {
 						const float r = __builtin_amdgcn_rcpf(det);
 						inv_det = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
 					} else inv_det = 1.0f / det;

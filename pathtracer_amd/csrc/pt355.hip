@@ -249,18 +249,24 @@ void carve_queue(PathQ &q, char *&p, uint32_t stride)
 }
 const uint32_t kQueueCols = 3 + 3 + 3 + 6 + 6 + 8 + 5 + 4 + 4;
 
+// the variant of k_trace for a launch: traversal counters, fused primary stage, IEEE division for 1/det (scenes whose
+// determinants can leave the range of the short reciprocal, see pt_upload_scene)
+typedef void (*trace_kernel_t)(TraceArgs);
+trace_kernel_t trace_kernel(bool count, bool gen, bool ieee_rcp)
+{
+	static const trace_kernel_t table[8] = {
+		k_trace<false, false, false>, k_trace<true, false, false>, k_trace<false, true, false>, k_trace<true, true, false>,
+		k_trace<false, false, true>,  k_trace<true, false, true>,  k_trace<false, true, true>,  k_trace<true, true, true>,
+	};
+	return table[(count ? 1 : 0) | (gen ? 2 : 0) | (ieee_rcp ? 4 : 0)];
+}
+
 int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = false)
 {
 	const bool timed = begin_timed(c, pp, 0);
 	const bool count = (c->cfg.flags & PT_FLAG_COUNT_TRAVERSAL) != 0;
 	const dim3 grid(c->trace_grid), block(PT_TRACE_BLOCK);
-	if (gen_primary) {
-		if (count) hipLaunchKernelGGL((k_trace<true, true>), grid, block, 0, pp.stream, ta);
-		else hipLaunchKernelGGL((k_trace<false, true>), grid, block, 0, pp.stream, ta);
-	} else if (count)
-		hipLaunchKernelGGL((k_trace<true, false>), grid, block, 0, pp.stream, ta);
-	else
-		hipLaunchKernelGGL((k_trace<false, false>), grid, block, 0, pp.stream, ta);
+	hipLaunchKernelGGL(trace_kernel(count, gen_primary, ta.sc.short_rcp == 0u), grid, block, 0, pp.stream, ta);
 	end_timed(c, pp, timed);
 	c->trace_launches++;
 	HIP_TRY(c, hipGetLastError());
@@ -348,7 +354,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	c->stream = c->pipe[0].stream;
 
 	int blocks_per_cu = 0;
-	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false, false>, PT_TRACE_BLOCK, 0));
+	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false, false, false>, PT_TRACE_BLOCK, 0));
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
 	// tuning knobs for experiments (tools/exp_*.py), read once per pt_create; defaults are the measured optimum (DESIGN.md
@@ -893,7 +899,7 @@ int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n,
 	ta.spill = sp->spill;
 	// the spill tail is sized for PT_NOALLOC_MAX_BLOCKS blocks: k_trace is persistent, any grid drains the work counters
 	const uint32_t grid = (uint32_t) c->trace_grid < PT_NOALLOC_MAX_BLOCKS ? (uint32_t) c->trace_grid : PT_NOALLOC_MAX_BLOCKS;
-	hipLaunchKernelGGL((k_trace<false, false>), dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
+	hipLaunchKernelGGL(trace_kernel(false, false, ta.sc.short_rcp == 0u), dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
 	HIP_TRY(c, hipGetLastError());
 	return PT_OK;
 }

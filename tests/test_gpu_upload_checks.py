@@ -81,6 +81,54 @@ def test_a_chain_deeper_than_the_stack_is_refused(pt):
     _upload_fails(pt, _desc_from(pt, base, nodes=nodes.view(np.uint32), tris=tris), "deeper than")
 
 
+def test_the_deepest_accepted_tree_fills_the_whole_stack(pt, ol):
+    """63 levels of pairs whose two children are both inner nodes with the scene's bounds (one continues the chain, the other
+    holds two one-triangle leaves): every ray that enters the box pushes at every level, so each lane's stack goes through
+    its LDS levels, through the whole spill tail and back down to the sentinel below its first entry.  Same hits as the oracle."""
+    base = pt.Scene.soup(128, seed=21, size=0.6).arrays()
+    tris = base["tris"]
+    v = tris.view(np.float32)[:, [0, 1, 2, 4, 5, 6, 8, 9, 10]].reshape(-1, 3)
+    lo, hi = v.min(0) - np.float32(0.01), v.max(0) + np.float32(0.01)
+    levels = 63
+    nodes = np.zeros((1 + 2 * levels + 4 * levels + 2, 8), np.float32)
+    nodes[:, 0:3] = lo; nodes[:, 4:7] = hi
+    nodes[0, 3] = 1.0
+    nxt = 1 + 2 * levels                      # where the leaf pairs start
+    t = 0
+    for k in range(levels):
+        a, b = 1 + 2 * k, 2 + 2 * k          # a continues the chain (or ends it in two leaves), b holds two leaves
+        for inner_node in ((b,) if k + 1 < levels else (a, b)):
+            nodes[inner_node, 3], nodes[inner_node, 7] = float(nxt), 0.0
+            for leaf in (nxt, nxt + 1):
+                nodes[leaf, 3], nodes[leaf, 7] = float(t), 1.0
+                t += 1
+            nxt += 2
+        if k + 1 < levels:
+            nodes[a, 3], nodes[a, 7] = float(1 + 2 * (k + 1)), 0.0
+    nodes = nodes[:nxt]
+    assert t == 128 and nodes.shape[0] % 2 == 1
+    d = _desc_from(pt, base, nodes=nodes.view(np.uint32), light_tris=np.zeros(0, np.uint32), spheres=np.zeros((0, 8), np.uint32),
+                   light_spheres=np.zeros(0, np.uint32))
+    rng = np.random.default_rng(3)
+    n = 20000
+    ro = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.5, 1.5, n), rng.uniform(-7.9, -4.1, n)], 1).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    c = pt.PathTracer(8, 8)
+    try:
+        c.upload_scene(d)
+        c.reset_counters()
+        prim, th, kind, uv = c.trace_closest(ro, rd)
+        spills = c.counters()["stack_spills"]
+    finally:
+        c.close()
+    oprim, oth, okind, ouv = ol.trace_closest(ol.scene_from_desc(d), ro, rd)
+    assert (okind == 1).mean() > 0.05
+    assert spills > 1000 * 40, spills      # the rays that enter the box spill some 50 entries each
+    assert np.array_equal(kind, okind) and np.array_equal(prim, oprim) and np.array_equal(th, oth)
+    assert np.array_equal(uv.view(np.uint32), ouv.view(np.uint32))
+
+
 def test_non_contiguous_sibling_leaves(pt, ol):
     """Foreign BVH: the two leaves of one pair point at triangle ranges that are far apart in the array."""
     base = pt.Scene.soup(64, seed=6, size=0.8).arrays()
