@@ -53,9 +53,6 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_TRACE_BLOCK 256
 #define PT_TRACE_MIN_WAVES 7
 #endif
-#ifndef PT_EXEC_LOOP
-#define PT_EXEC_LOOP 1 // the traversal loop as a divergent loop of the active lanes (a retiring lane breaks out) instead of a wave-uniform loop around if (active)
-#endif
 #define PT_SPILL_STACK (64 - PT_SHORT_STACK) // together 64 = the builder's max_depth (top_down_builder.hpp:36)
 #define PT_TRACE_WAVES (PT_TRACE_BLOCK / 64)
 #define PT_TOP_RECORDS (PT_TOP_BYTES / 64)
@@ -277,7 +274,6 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	const bool have_tree = a.sc.n_records != 0u;
 
 	// per-lane ray state
-	bool active = false;
 	uint4 *hitp = nullptr;
 	v3 ro = V(0, 0, 0), rd = V(0, 0, 0), inv = V(0, 0, 0);
 	float tmax = PT_TMAX;
@@ -294,6 +290,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	uint32_t shard_count = 0, shard_units = 0;
 	bool shard_known = false;
 
+	// a lane is busy while it has a record to visit or triangles pending; finished, refused and never-filled lanes all look alike
+	auto is_active = [&]() { return tri < tri_end || cur != PT_CUR_DONE; };
 	// One N step on the record (q0..q3) for this lane's ray: fc:352-418 minus the triangle loop (see k_trace's header).
 	auto node_step = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
 		if (COUNT) n_steps++;
@@ -335,18 +333,26 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 			if (__builtin_expect(sp > PT_SHORT_STACK, 0)) cur = spill[(sp - (PT_SHORT_STACK + 1u)) * 64u]; // rare: keeps the common pop a plain ds_read
 		}
 	};
-	// Retire the lane's ray: the hoisted sphere result competes with the traversal's (fc:447: TMIN <= t <= tmax).
-	auto retire = [&]() {
-		if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
-		pt_u32x4 rec;
-		rec.x = best_prim; rec.y = best_tk; rec.z = __float_as_uint(best_u); rec.w = __float_as_uint(best_v);
-		PT_NT_STORE(rec, (pt_u32x4 *) hitp);
-		active = false;
+	// Write out the record of a lane whose ray has finished: the hoisted sphere result competes with the traversal's (fc:447:
+	// TMIN <= t <= tmax).  NOT done inside the traversal loop: a finished lane just leaves it with its result in its registers
+	// (nothing touches them while it idles) and the records of all of them go out in one store instruction before the next
+	// refill.  Inside the loop the store sat in front of the next iteration's loads in the wave's one vector-memory counter, so
+	// every s_waitcnt for a record fetch also waited for a write acknowledgement -- in almost every iteration, since about
+	// three lanes of a wave finish per iteration.
+	auto flush_finished = [&]() {
+		if (hitp && !is_active()) {
+			if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
+			pt_u32x4 rec;
+			rec.x = best_prim; rec.y = best_tk; rec.z = __float_as_uint(best_u); rec.w = __float_as_uint(best_v);
+			PT_NT_STORE(rec, (pt_u32x4 *) hitp);
+			hitp = nullptr;
+		}
 	};
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill idle lanes
-		const unsigned long long idle = __ballot(!active);
+		flush_finished();
+		const unsigned long long idle = __ballot(!is_active());
 		const uint32_t n_idle = (uint32_t) __popcll(idle);
 		if (!exhausted && n_idle > 0u && (n_idle == 64u || n_idle >= a.refill_threshold)) {
 			if (loc_next == loc_end) {
@@ -384,16 +390,17 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 			const uint32_t take = n_idle < avail ? n_idle : avail;
 			const uint32_t base = loc_next;
 			loc_next += take;
-			if (!active) {
+			if (!is_active()) {
 				const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle, 0u));
 				if (rank < take) {
 					const uint32_t slot = base + rank;
 					const RaySeg &rs = a.seg[loc_seg];
-					hitp = rs.hit + slot; // where this ray's record goes: kept per lane so that retiring is a store, not a load of the segment table first
+					hitp = nullptr; // stays so for a slot without a ray: nothing to write
 					// queue columns are read once and streamed: non-temporal, so that they do not push the traversal blob out of
 					// the XCD's 4 MiB L2 (PT_NT below; measured in profiles/r02_*)
 					bool ok = (!GEN && rs.valid) ? (PT_NT_LOAD(&rs.valid[slot]) & 1u) != 0 : true;
 					if (ok) {
+						hitp = rs.hit + slot; // where this ray's record goes: kept per lane, so that writing it later needs no look at the segment table
 						const uint32_t st = a.stride;
 						v3 fro, frd;
 						if (GEN) {
@@ -445,36 +452,34 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						if (occluded_now) {
 							if (a.shadow_mode == PT_SHADOW_ANYHIT) sph_tk = (sph_tk & 0xffffu) | (3u << 16);
 							*hitp = make_uint4(sph_prim, sph_tk, 0u, 0u);
+							hitp = nullptr;
 						} else if (have_tree) {
-							cur = 0u; active = true;
+							cur = 0u; // the root pair's record: the lane is active from here on
+						} else {
+							*hitp = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
+							hitp = nullptr;
 						}
-						else *hitp = make_uint4(sph_tk ? sph_prim : 0xffffffffu, sph_tk, 0u, 0u);
 					}
 				}
 			}
 		}
-		if (__ballot(active) == 0ull) {
+		if (__ballot(is_active()) == 0ull) {
 			if (exhausted) break;
 			continue;
 		}
 
 		// ------------------------------------------------------------------ traverse until enough lanes go idle
-		for (;;) {
+		{
 			// every active lane has work: pending triangles (T) or a record to visit (N); lanes retire at once
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
 			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form, and again
 			// 1.5-5 % slower at 4/8/16 lanes after the tree top moved to LDS -- DESIGN.md "What was tried".)
-#if PT_EXEC_LOOP
 			uint32_t my_iters = 0;
 			// leave for a refill once no more than this many lanes are still traversing (never, once the queue is dry); one scalar
 			// for the whole loop: `exhausted` cannot change inside it
 			const int live_min = __builtin_amdgcn_readfirstlane(exhausted ? -1 : 64 - (int) a.refill_threshold);
-			if (active) for (;;) {
+			if (is_active()) for (;;) {
 				if (COUNT) my_iters++;
-#else
-			if (COUNT) n_iters++;
-			if (active) {
-#endif
 				const bool tmode = tri < tri_end;
 				const uint32_t off = tmode ? tri : cur;
 				float4 q0, q1, q2, q3;
@@ -550,24 +555,15 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						}
 					}
 				} else node_step(q0, q1, q2, q3);
-#if PT_EXEC_LOOP
 				// a retiring lane leaves the loop (its exec bit drops until the others follow); the rest go round again unless
 				// enough of the wave has gone idle for a refill
-				if (tri >= tri_end && cur == PT_CUR_DONE) { retire(); break; }
+				if (!is_active()) break;
 				if ((int) __popcll(__ballot(true)) <= live_min) break;
 			}
 			if (COUNT) {
 				for (int o = 32; o > 0; o >>= 1) { const uint32_t other = __shfl_xor(my_iters, o); my_iters = other > my_iters ? other : my_iters; }
 				n_iters += my_iters;
 			}
-			break;
-#else
-				if (tri >= tri_end && cur == PT_CUR_DONE) retire();
-			}
-			const unsigned long long act = __ballot(active);
-			if (act == 0ull) break;
-			if (!exhausted && (64u - (uint32_t) __popcll(act)) >= a.refill_threshold) break;
-#endif
 		}
 	}
 
