@@ -45,7 +45,7 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_SHORT_STACK 12
 #endif
 #ifndef PT_TRACE_BLOCK
-#define PT_TRACE_BLOCK 1024 // 16 waves share one copy of the tree top: 16 * 3.25 KB of stacks + 16 KB = 68 KB, two blocks per CU
+#define PT_TRACE_BLOCK 1024 // 16 waves share one copy of the tree top: 16 * 3.5 KB of stacks + 16 KB = 72 KB, two blocks per CU
 #endif
 #define PT_TRACE_MIN_WAVES 8 // two such blocks per CU need 8 waves per SIMD: at most 64 VGPRs
 #else
@@ -252,8 +252,9 @@ template <bool COUNT, bool GEN, bool IEEE_RCP>
 __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(TraceArgs a)
 {
 	// level 0 of every lane's stack holds PT_CUR_DONE for good and sp starts at 1: popping the last entry needs no test for an
-	// empty stack, the lane just reads "done"
-	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK + 1][64];
+	// empty stack, the lane just reads "done".  Level PT_SHORT_STACK + 1 is a dump: a push beyond the LDS levels lands there
+	// (and, for real, in the spill tail), so the common push is one unconditional ds_write instead of a two-way branch.
+	__shared__ uint32_t s_stack[PT_TRACE_WAVES][PT_SHORT_STACK + 2][64];
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 	uint32_t *const lds = &s_stack[wave][0][lane];
 	lds[0] = PT_CUR_DONE;
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 		const uint32_t nearer = r_first ? c_r : c_l, farther = r_first ? c_l : c_r;
 		cur = both ? nearer : (go_l ? c_l : c_r);
 		if (both) {
-			if (__builtin_expect(sp <= PT_SHORT_STACK, 1)) lds[sp * 64u] = farther;
-			else { spill[(sp - (PT_SHORT_STACK + 1u)) * 64u] = farther; n_spills++; } // sp <= 64: pt_upload_scene bounds the depth
+			lds[(sp <= PT_SHORT_STACK ? sp : PT_SHORT_STACK + 1u) * 64u] = farther;
+			if (__builtin_expect(sp > PT_SHORT_STACK, 0)) { spill[(sp - (PT_SHORT_STACK + 1u)) * 64u] = farther; n_spills++; } // sp <= 64: pt_upload_scene bounds the depth
 			sp++;
 		}
 		if (!any) {
