@@ -6,8 +6,11 @@
 //  * a lane alternates between node steps and single-triangle tests; both fetch 64 aligned bytes, so every wave
 //    iteration is one memory round trip in which every active lane makes progress (see k_trace below);
 //  * traversal stack: PT_SHORT_STACK entries per lane in LDS, laid out [level][lane] so that a
-//    wave-wide push/pop is bank-conflict free whatever the per-lane depth; deeper pushes spill to a
-//    per-wave HBM tail (counted in pt_counters.stack_spills; the reference has 16 slots and no check);
+//    wave-wide push/pop is bank-conflict free whatever the per-lane depth, between a sentinel level that reads "done"
+//    and a dump level that takes the pushes beyond; those spill to a per-wave HBM tail (counted in
+//    pt_counters.stack_spills; the reference has 16 slots and no check);
+//  * a finished lane leaves the traversal loop with its result in registers; the hit records of all finished lanes
+//    are written by one store in front of the next refill;
 //  * the kernel walks its own copy of the BVH, built at upload ("traversal blob", below): one 64-byte record per
 //    inner node with both children's bounds and integer links, and 64-byte triangle records with the edges already
 //    subtracted -> 4 x dwordx4 per lane per step from ONE base pointer with 32-bit offsets;
@@ -33,9 +36,10 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 
 // The top of the tree lives in LDS: the first PT_TOP_BYTES of the traversal blob (build_traversal_blob puts the records
 // with the largest boxes there) are copied into every block's LDS at kernel start, and a lane whose record lies in that
-// range reads it with ds_read_b128 instead of global_load_dwordx4.  The kernel is bound by the vector-memory path's rate
-// of divergent 16-byte lane accesses (tools/ubench_gather.hip: 0.69 clk per lane and instruction whether they hit L1 or
-// not); every ray passes through the top levels, so this takes about half of those accesses off that path.
+// range reads it with ds_read_b128 instead of global_load_dwordx4.  Without it the kernel sits on the vector-memory path's
+// rate of divergent 16-byte lane accesses (tools/ubench_gather.hip: 0.69 clk per lane and instruction whether they hit L1
+// or not); every ray passes through the top levels, so this takes 63 % of those accesses off that path (bench scene) and
+// leaves the kernel bound by its own instruction stream (k_trace).
 // 0 = off (every record from global memory).
 #ifndef PT_TOP_BYTES
 #define PT_TOP_BYTES 16384
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 
 		// ------------------------------------------------------------------ traverse until enough lanes go idle
 		{
-			// every active lane has work: pending triangles (T) or a record to visit (N); lanes retire at once
+			// every active lane has work: pending triangles (T) or a record to visit (N); a lane leaves as soon as it has neither
 			// (Holding lanes with a pending triangle back until 4..48 of them had gathered, so that the triangle block
 			// runs on a fuller wave, was measured 2-38 % slower in both a stalling and a non-stalling form, and again
 			// 1.5-5 % slower at 4/8/16 lanes after the tree top moved to LDS -- DESIGN.md "What was tried".)
@@ -485,9 +489,11 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 				const uint32_t off = tmode ? tri : cur;
 				float4 q0, q1, q2, q3;
 #if PT_TOP_BYTES
-				// two exec-masked load groups (global_load_dwordx4 for the lanes below the top, ds_read_b128 for the others), issued
-				// back to back and awaited together.  The empty asm keeps the two branches apart: merged into one select of a generic
-				// pointer they become flat_load instructions, which take every lane through the vector-memory front end again.
+				// two exec-masked load groups: global_load_dwordx4 for the lanes below the top, ds_read_b128 for the others.  The
+				// empty asm keeps the two branches apart: merged into one select of a generic pointer they become flat_load
+				// instructions, which take every lane through the vector-memory front end again.  (The compiler cannot know that the
+				// groups write disjoint lanes of the same registers and waits for the global loads before it issues the LDS reads;
+				// the same fetch written in asm with both groups in flight together measured +-0, DESIGN.md "What was tried".)
 				if (off >= top_bytes) {
 					const float4 *p = (const float4 *) (blob + off);
 					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
