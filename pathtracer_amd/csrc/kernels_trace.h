@@ -356,6 +356,18 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 
 	for (;;) {
 		// ------------------------------------------------------------------ refill idle lanes
+		// The wave's work state is the same in every lane.  The compiler cannot see that through the loops around it and keeps it
+		// in vector registers with lane masks for the flags; read back through v_readfirstlane it lives in scalar registers and
+		// the unit bookkeeping below is scalar code (8 VGPRs fewer, no spill in the ray-generating variant, k_trace -3.7 %).
+		exhausted = __builtin_amdgcn_readfirstlane((int) exhausted) != 0;
+		shard_known = __builtin_amdgcn_readfirstlane((int) shard_known) != 0;
+		loc_next = (uint32_t) __builtin_amdgcn_readfirstlane((int) loc_next);
+		loc_end = (uint32_t) __builtin_amdgcn_readfirstlane((int) loc_end);
+		loc_seg = (uint32_t) __builtin_amdgcn_readfirstlane((int) loc_seg);
+		shard = (uint32_t) __builtin_amdgcn_readfirstlane((int) shard);
+		shards_done = (uint32_t) __builtin_amdgcn_readfirstlane((int) shards_done);
+		shard_count = (uint32_t) __builtin_amdgcn_readfirstlane((int) shard_count);
+		shard_units = (uint32_t) __builtin_amdgcn_readfirstlane((int) shard_units);
 		flush_finished();
 		const unsigned long long idle = __ballot(!is_active());
 		const uint32_t n_idle = (uint32_t) __popcll(idle);
