@@ -338,6 +338,57 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 			if (__builtin_expect(sp > PT_SHORT_STACK, 0)) cur = spill[(sp - (PT_SHORT_STACK + 1u)) * 64u]; // rare: keeps the common pop a plain ds_read
 		}
 	};
+	// One T step: intersect_triangle, fc:271-292, on the triangle record (q0..q2) -- the attributes are resolved by the shading kernel.
+	auto tri_step = [&](const float4 q0, const float4 q1, const float4 q2) {
+#ifdef PT_EXP_DUP_T
+		{ // diagnostic only: the triangle arithmetic a second time on a perturbed ray, result kept alive but never used
+			const v3 rd2 = V(rd.x + 1.0f, rd.y, rd.z), ro2 = V(ro.x, ro.y + 1.0f, ro.z);
+			const v3 xv0 = V(q0.x, q0.y, q0.z), xe1 = V(q1.x, q1.y, q1.z), xe2 = V(q2.x, q2.y, q2.z);
+			const v3 xpv = cross(rd2, xe2);
+			const float xdet = dot(xe1, xpv), xinv = 1.0f / xdet;
+			const v3 xtv = ro2 - xv0;
+			const float xu = dot(xtv, xpv) * xinv;
+			const v3 xqv = cross(xtv, xe1);
+			const float xv = xinv * dot(rd2, xqv), xt = xinv * dot(xe2, xqv);
+			if (xu + xv + xt == 12345.678f) best_u = xt;
+		}
+#endif
+		// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
+		if (COUNT) n_tests++;
+		tri += 64u;
+		const v3 v0 = V(q0.x, q0.y, q0.z);
+		const v3 e1 = V(q1.x, q1.y, q1.z);
+		const v3 e2 = V(q2.x, q2.y, q2.z);
+		const v3 pv = cross(rd, e2);
+		const float det = dot(e1, pv);
+		// 1/det.  v_rcp_f32 + one FMA Newton step (3 instructions for the 12 of the correctly rounded division) returns
+		// the SAME bits as the IEEE division for every normal |x| < 2^126 -- all 4.26e9 of them checked
+		// (tools/verify_rcp.hip, profiles/r01g_verify_rcp.txt); a smaller |det| is rejected below whatever its
+		// reciprocal, and pt_upload_scene sets short_rcp only when no triangle's edges can produce a larger one.
+		float inv_det;
+		if (!IEEE_RCP) {
+			const float r = __builtin_amdgcn_rcpf(det);
+			inv_det = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
+		} else inv_det = 1.0f / det;
+		const v3 tv = ro - v0;
+		const float u = dot(tv, pv) * inv_det;
+		if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {
+			const v3 qv = cross(tv, e1);
+			const float v = inv_det * dot(rd, qv);
+			const float t = inv_det * dot(e2, qv);
+			if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
+				const h16 th = to_h16(t);
+				tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
+				best_prim = __float_as_uint(q0.w);
+				best_tk = h_bits(th) | (1u << 16);
+				best_u = u; best_v = v;
+				if (tmax <= t_kill) { // shadow ray decided: nothing closer can change the verdict
+					tri = tri_end; cur = PT_CUR_DONE; sph_tk = 0u;
+					if (a.shadow_mode == PT_SHADOW_ANYHIT) best_tk = (best_tk & 0xffffu) | (3u << 16);
+				}
+			}
+		}
+	};
 	// Write out the record of a lane whose ray has finished: the hoisted sphere result competes with the traversal's (fc:447:
 	// TMIN <= t <= tmax).  NOT done inside the traversal loop: a finished lane just leaves it with its result in its registers
 	// (nothing touches them while it idles) and the records of all of them go out in one store instruction before the next
@@ -520,60 +571,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					const float4 *p = (const float4 *) (blob + off);
 					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
 				}
-#endif
 				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
 				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
-				if (tmode) {
-#ifdef PT_EXP_DUP_T
-					{ // diagnostic only: the triangle arithmetic a second time on a perturbed ray, result kept alive but never used
-						const v3 rd2 = V(rd.x + 1.0f, rd.y, rd.z), ro2 = V(ro.x, ro.y + 1.0f, ro.z);
-						const v3 xv0 = V(q0.x, q0.y, q0.z), xe1 = V(q1.x, q1.y, q1.z), xe2 = V(q2.x, q2.y, q2.z);
-						const v3 xpv = cross(rd2, xe2);
-						const float xdet = dot(xe1, xpv), xinv = 1.0f / xdet;
-						const v3 xtv = ro2 - xv0;
-						const float xu = dot(xtv, xpv) * xinv;
-						const v3 xqv = cross(xtv, xe1);
-						const float xv = xinv * dot(rd2, xqv), xt = xinv * dot(xe2, xqv);
-						if (xu + xv + xt == 12345.678f) best_u = xt;
-					}
+				if (tmode) tri_step(q0, q1, q2);
+				else node_step(q0, q1, q2, q3);
 #endif
-					// intersect_triangle, fc:271-292 (attributes are resolved by the shading kernel)
-					if (COUNT) n_tests++;
-					tri += 64u;
-					const v3 v0 = V(q0.x, q0.y, q0.z);
-					const v3 e1 = V(q1.x, q1.y, q1.z);
-					const v3 e2 = V(q2.x, q2.y, q2.z);
-					const v3 pv = cross(rd, e2);
-					const float det = dot(e1, pv);
-					// 1/det.  v_rcp_f32 + one FMA Newton step (3 instructions for the 12 of the correctly rounded division) returns
-					// the SAME bits as the IEEE division for every normal |x| < 2^126 -- all 4.26e9 of them checked
-					// (tools/verify_rcp.hip, profiles/r01g_verify_rcp.txt); a smaller |det| is rejected below whatever its
-					// reciprocal, and pt_upload_scene sets short_rcp only when no triangle's edges can produce a larger one.
-					float inv_det;
-					if (!IEEE_RCP) {
-						const float r = __builtin_amdgcn_rcpf(det);
-						inv_det = __builtin_fmaf(__builtin_fmaf(-det, r, 1.0f), r, r);
-					} else inv_det = 1.0f / det;
-					const v3 tv = ro - v0;
-					const float u = dot(tv, pv) * inv_det;
-					if (!(__builtin_fabsf(det) < PT_EPSILON || u < 0.0f || u > 1.0f)) {
-						const v3 qv = cross(tv, e1);
-						const float v = inv_det * dot(rd, qv);
-						const float t = inv_det * dot(e2, qv);
-						if (v >= 0.0f && u + v <= 1.0f && t > PT_TMIN && t < tmax) {
-							const h16 th = to_h16(t);
-							tmax = (float) th;           // fc:375: tmax = local_data.t (float16_t)
-							best_prim = __float_as_uint(q0.w);
-							best_tk = h_bits(th) | (1u << 16);
-							best_u = u; best_v = v;
-							if (tmax <= t_kill) { // shadow ray decided: nothing closer can change the verdict
-								tri = tri_end; cur = PT_CUR_DONE; sph_tk = 0u;
-								if (a.shadow_mode == PT_SHADOW_ANYHIT) best_tk = (best_tk & 0xffffu) | (3u << 16);
-							}
-						}
-					}
-				} else node_step(q0, q1, q2, q3);
 				// a retiring lane leaves the loop (its exec bit drops until the others follow); the rest go round again unless
 				// enough of the wave has gone idle for a refill
 				if (!is_active()) break;
