@@ -571,12 +571,12 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					const float4 *p = (const float4 *) (blob + off);
 					q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
 				}
+#endif
 				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
 				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
 				if (tmode) tri_step(q0, q1, q2);
 				else node_step(q0, q1, q2, q3);
-#endif
 				// a retiring lane leaves the loop (its exec bit drops until the others follow); the rest go round again unless
 				// enough of the wave has gone idle for a refill
 				if (!is_active()) break;
