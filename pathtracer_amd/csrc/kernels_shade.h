@@ -27,7 +27,7 @@ struct PathQ {
 	float *thr;      // 3: throughput_term
 	float *col;      // 3: color so far
 	float *ray;      // 6: bounce ray ro, rd                                      (trace segment 0)
-	float *sray;     // 6: shadow ray origin x, direction                         (trace segment 1)
+	float *sray;     // 6: shadow ray origin x; direction only in k_shade_alt's stages (trace segment 1 rebuilds it from x and y_nee)
 	float *nee;      // 8: P = Le*BRDF*cos_x (3), A = pdf_light_area*d^2, pdf_BSDF(nee), y_nee (3)
 	float *bs;       // 5: BRDF (3), cos_theta_x, pdf_BSDF_sa of the sampled direction
 	uint4 *hit;      // closest hit of the bounce ray, one 16-byte record: (prim, t_h|kind<<16, u, v)
@@ -528,7 +528,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 			thr = V(1.0f, 1.0f, 1.0f);
 		} else {
 			pixel = PT_QLD(&a.in.pix[i]); rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
-			thr = ld3(a.in.thr, i, st); col = ld3(a.in.col, i, st);
+			// stage 0 never touches the throughput (fc:874-897: it is first multiplied at fc:1069), so the stage after it knows
+			// it is 1 and stage 0 does not write it: 12 B per path less on either side
+			thr = a.stage == 1u ? V(1.0f, 1.0f, 1.0f) : ld3(a.in.thr, i, st);
+			col = ld3(a.in.col, i, st);
 			ro = ld3(a.in.ray, i, st); rd = ld3(a.in.ray + 3 * (size_t) st, i, st);
 		}
 		const uint4 hrec = ldq4(&a.in.hit[i]);
@@ -555,10 +558,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 				const uint4 srec = ldq4(&a.in.shit[i]);
 				const uint32_t sp_ = srec.x, stk = srec.y;
 				if ((stk >> 16) != 0u && (stk >> 16) != 3u) { // kind 3: an any-hit traversal already found an occluder
-					const v3 sro = ld3(a.in.sray, i, st), srd = ld3(a.in.sray + 3 * (size_t) st, i, st);
+					const v3 sro = ld3(a.in.sray, i, st);
+					const v3 y_nee = ld3(a.in.nee + 5 * (size_t) st, i, st);
+					const v3 srd = normalize(y_nee - sro); // fc:959-960 again, bit for bit: the direction is not kept in the queue
 					const float su = __uint_as_float(srec.z), sv = __uint_as_float(srec.w);
 					const HitRec sh = hit_attributes(sc, sp_, stk, su, sv, sro, srd);
-					const v3 y_nee = ld3(a.in.nee + 5 * (size_t) st, i, st);
 					const v3 dlt = y_nee - (sro + srd * sh.t);
 					if (dlt.x < PT_FLOAT_COMPARE && dlt.y < PT_FLOAT_COMPARE && dlt.z < PT_FLOAT_COMPARE) {
 						const float cos_theta_y = dot(sh.n, -srd);
@@ -646,8 +650,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 		const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, true);
 		const v3 P = le * brdf * cos_theta_x;
 		const float pdf_light_area = pdf_pick_light * (1.0f / light_area);
-		st3(a.out.sray, o, st, x);
-		st3(a.out.sray + 3 * (size_t) st, o, st, shadow_rd);
+		st3(a.out.sray, o, st, x); // the direction is rebuilt from x and y_nee where it is needed (k_trace refill, next stage)
 		st3(a.out.nee, o, st, P);
 		PT_QST(pdf_light_area * squared_dist, &a.out.nee[3 * (size_t) st + o]);
 		PT_QST(cos_theta_x / PT_PI, &a.out.nee[4 * (size_t) st + o]);
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	PT_QST(pixel, &a.out.pix[o]);
 	PT_QST(rng, &a.out.rng[o]);
 	PT_QST(new_meta, &a.out.meta[o]);
-	st3(a.out.thr, o, st, thr);
+	if (!(PRIMARY || a.stage == 0u)) st3(a.out.thr, o, st, thr); // stage 0: still 1, see above
 	st3(a.out.col, o, st, col);
 	st3(a.out.ray, o, st, new_ro);
 	st3(a.out.ray + 3 * (size_t) st, o, st, new_rd);

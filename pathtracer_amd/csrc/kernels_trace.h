@@ -156,7 +156,8 @@ struct RaySeg {
 	const float *ray;
 	uint4 *hit;
 	const uint32_t *valid; // optional: bit0 of valid[i] says the slot holds a ray (shadow segment)
-	const float *target;   // optional (shadow segment): target[c*stride + i], c = 0..2 = the light sample y_nee the ray aims at
+	const float *target;   // optional (shadow segment): target[c*stride + i], c = 0..2 = the light sample y_nee the ray aims at; such a
+	                       // segment's ray columns hold the origin only, the direction is normalize(target - origin)
 };
 
 struct TraceArgs {
@@ -470,14 +471,21 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 					if (ok) {
 						hitp = rs.hit + slot; // where this ray's record goes: kept per lane, so that writing it later needs no look at the segment table
 						const uint32_t st = a.stride;
-						v3 fro, frd;
+						v3 fro, frd, fy = V(0, 0, 0);
 						if (GEN) {
 							uint32_t rng_unused;
 							primary_ray(a, slot, &fro, &frd, &rng_unused); // the camera ray of path `slot`: nothing to read
 						} else {
 							const float *r = rs.ray + slot;
 							fro = V(PT_NT_LOAD(&r[0]), PT_NT_LOAD(&r[st]), PT_NT_LOAD(&r[2 * st]));
-							frd = V(PT_NT_LOAD(&r[3 * st]), PT_NT_LOAD(&r[4 * st]), PT_NT_LOAD(&r[5 * st]));
+							if (rs.target) {
+								// a shadow ray's direction is not in the queue: it is normalize(y_nee - x) (fc:959-960), the expression the
+								// shading kernel used and will use again, from the two points that are (12 B less per shadow ray written
+								// once and read twice)
+								const float *tg = rs.target + slot;
+								fy = V(PT_NT_LOAD(&tg[0]), PT_NT_LOAD(&tg[st]), PT_NT_LOAD(&tg[2 * st]));
+								frd = normalize(fy - fro);
+							} else frd = V(PT_NT_LOAD(&r[3 * st]), PT_NT_LOAD(&r[4 * st]), PT_NT_LOAD(&r[5 * st]));
 						}
 						// Sphere loop of fc:439-453, hoisted in front of the traversal while the full-precision ray is in
 						// registers.  The loop only compares against tmax, so its outcome is: the LAST sphere attaining the
@@ -497,8 +505,7 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						t_kill = -__builtin_inff();
 						bool occluded_now = false;
 						if (!GEN && rs.target && a.shadow_mode != PT_SHADOW_FULL) {
-							const float *tg = rs.target + slot;
-							const v3 y = V(PT_NT_LOAD(&tg[0]), PT_NT_LOAD(&tg[st]), PT_NT_LOAD(&tg[2 * st]));
+							const v3 y = fy;
 							t_kill = fmax_(shadow_kill_component(y.x, fro.x, frd.x),
 							               fmax_(shadow_kill_component(y.y, fro.y, frd.y), shadow_kill_component(y.z, fro.z, frd.z)));
 							if (a.shadow_mode == PT_SHADOW_ANYHIT) {
