@@ -21,9 +21,9 @@
 
 // columns of one path queue; every array has `stride` entries per component
 struct PathQ {
-	uint32_t *pix;   // path id in the batch: frame_slot * n_paths_frame + path-in-frame (k_raygen order)
+	uint32_t *pix;   // path id in the batch: frame_slot * n_paths_frame + path-in-frame (k_raygen order); k_shade's own stages keep it in `meta`
 	uint32_t *rng;   // PCG state
-	uint32_t *meta;  // bit0: shadow ray present, bit1: can_use_NEE at x, bit2: material at x is SPECULAR_METAL
+	uint32_t *meta;  // bit0: shadow ray present, bit1: can_use_NEE at x, bit2: material at x is SPECULAR_METAL; k_shade: path id << 4 above them
 	float *thr;      // 3: throughput_term
 	float *col;      // 3: color so far
 	float *ray;      // 6: bounce ray ro, rd                                      (trace segment 0)
@@ -527,7 +527,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 			primary_ray(a, i, &ro, &rd, &rng);
 			thr = V(1.0f, 1.0f, 1.0f);
 		} else {
-			pixel = PT_QLD(&a.in.pix[i]); rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
+			// the stages of this kernel keep path id and flags in ONE word, (id << 4) | flags, in the meta column (bit 0 is what
+			// the trace kernel reads); only k_raygen's output (stage 0 of the unfused form) has them apart
+			rng = PT_QLD(&a.in.rng[i]); meta = PT_QLD(&a.in.meta[i]);
+			if (a.stage == 0u) pixel = PT_QLD(&a.in.pix[i]);
+			else { pixel = meta >> 4; meta &= 15u; }
 			// stage 0 never touches the throughput (fc:874-897: it is first multiplied at fc:1069), so the stage after it knows
 			// it is 1 and stage 0 does not write it: 12 B per path less on either side
 			thr = a.stage == 1u ? V(1.0f, 1.0f, 1.0f) : ld3(a.in.thr, i, st);
@@ -664,9 +668,8 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	const v3 new_rd = normalize(mul(inverse_tnb, wi));
 	const v3 brdf = calc_brdf(sc, wo, wm, wi, mat_x, data.uvx, data.uvy, false);
 
-	PT_QST(pixel, &a.out.pix[o]);
 	PT_QST(rng, &a.out.rng[o]);
-	PT_QST(new_meta, &a.out.meta[o]);
+	PT_QST((pixel << 4) | new_meta, &a.out.meta[o]); // path ids stay below 2^28: pt_create takes at most 16384 x 16384 pixels, and caps a launch set of several frames at 2^26 paths
 	if (!(PRIMARY || a.stage == 0u)) st3(a.out.thr, o, st, thr); // stage 0: still 1, see above
 	st3(a.out.col, o, st, col);
 	st3(a.out.ray, o, st, new_ro);
