@@ -390,6 +390,17 @@ def main():
                 "node_steps_per_ray": round(S, 3), "tri_tests_per_ray": round(T, 3),
                 "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_launch_ms, 4),
                 "trace_ms_total": round(cnt["ms_trace"], 3), "shade_ms_total": round(cnt["ms_shade"], 3)})
+    # the other third of the frame: k_shade (+ its primary form and k_resolve) IS bound by HBM bytes -- PMC bytes per launch of the same
+    # workload over the HIP-event time of these kernels in the timed region
+    if have_pmc and all(k in pmc["kernels"] for k in ("k_shade", "k_shade<primary>", "k_resolve")) and cnt["ms_shade"] > 0:
+        n_sets = launches / float(args.bounces + 1)  # launch sets (batches) in the timed region
+        rscale = rays_per_launch / max(pk.get("rays_per_launch", 0.0), 1.0)  # as for `traffic`: the profiled batch may differ in size
+        sbytes = rscale * n_sets * (args.bounces * pmc["kernels"]["k_shade"]["hbm_bytes_per_launch"] + pmc["kernels"]["k_shade<primary>"]["hbm_bytes_per_launch"]
+                           + pmc["kernels"]["k_resolve"]["hbm_bytes_per_launch"])
+        sgbs = sbytes / (cnt["ms_shade"] * 1e-3) / 1e9
+        roofline["shading_kernels"] = {"kernels": "k_shade<primary> + bounces x k_shade + k_resolve", "bound": "hbm", "achieved": round(sgbs, 1), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(sgbs / HBM_PEAK_GBS, 4), "traffic_per_launch_set": round(sbytes / n_sets),
+                                       "note": "HBM-side bytes from the PMC passes (same source as `traffic`); a plain 32-column read+write copy reaches 5350 GB/s on this chip (tools/ubench_soa.hip)"}
 
     cpu = None
     if not args.no_cpu_baseline and world == 1:
