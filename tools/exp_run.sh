@@ -7,7 +7,7 @@ mkdir -p gpurun_out
 for n in "$@"; do
 	for rep in 1 2; do
 		echo -n "$n " >> gpurun_out/exp.log
-		timeout -k 10 120 ./exp/$n/ptbench $FRAMES >> gpurun_out/exp.log 2>&1 || { echo "FAILED $n" >> gpurun_out/exp.log; cat gpurun_out/exp.log; exit 1; }
+		timeout -k 5 45 ./exp/$n/ptbench $FRAMES >> gpurun_out/exp.log 2>&1 || { echo "FAILED $n" >> gpurun_out/exp.log; cat gpurun_out/exp.log; exit 1; }
 	done
 done
 cat gpurun_out/exp.log
