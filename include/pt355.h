@@ -148,11 +148,16 @@ int pt_framebuffer_device(pt_ctx *ctx, void **dev_ptr);
 
 /* Test / bench boundary for the bit-exact closest-hit contract: intersect() of
  * framebuffer.comp:423-456 for n rays (AoS xyz, host memory).  kind: 0 miss, 1 triangle, 2 sphere;
- * prim: full 32-bit primitive index; t_h: fp16 bits of HitData.t; uv: optional, 2 floats per ray. */
+ * prim: full 32-bit primitive index; t_h: fp16 bits of HitData.t; uv: optional, 2 floats per ray --
+ * kind 1: the barycentrics (u, v) of the accepted triangle, from which framebuffer.comp:294-310 derives uvs and
+ * normal; kind 2: HitData.uvs itself, widened to float -- the sphere branch (framebuffer.comp:447-451) does not
+ * write uvs, so they are those of the last triangle the BVH pass accepted (0 if none), and calc_BRDF textures the
+ * sphere's material with them (framebuffer.comp:599-603); kind 0: 0. */
 int pt_trace_closest(pt_ctx *ctx, const float *ro, const float *rd, uint32_t n,
                      uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv);
 /* Same kernel on rays already resident in HBM: ray6 = structure-of-arrays ro.x[n] ro.y[n] ro.z[n] rd.x[n] rd.y[n]
- * rd.z[n]; hit4 = one 16-byte record per ray, 16-byte aligned: {prim u32, t_h | kind<<16, u f32, v f32}.  Asynchronous. */
+ * rd.z[n]; hit4 = one 16-byte record per ray, 16-byte aligned: {prim u32, t_h | kind<<16, u f32, v f32}; a sphere's
+ * record is {sphere u32, t_h | 2<<16, HitData.uvs as fp16 bits x | y<<16, 0}.  Asynchronous. */
 int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
 
 /* No counterpart in the reference.  pt_trace_closest_device for callers that cannot allocate: code under HIP graph

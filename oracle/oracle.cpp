@@ -996,7 +996,12 @@ int oracle_trace_closest(const oracle_scene *s, const float *ro, const float *rd
 		kind[i] = hit ? (uint8_t) (h.type + 1) : 0;
 		prim[i] = hit ? h.obj32 : 0xffffffffu;
 		t_h[i] = hit ? h.t : 0;
-		if (uv) { uv[2 * i] = hit && h.type == 0 ? h.u : 0.0f; uv[2 * i + 1] = hit && h.type == 0 ? h.v : 0.0f; }
+		if (uv) {
+			// triangle: the barycentrics; sphere: HitData.uvs as the shader leaves them (fc:447-451 does not write uvs, so they
+			// are the last accepted triangle's, or the zeroed record's)
+			uv[2 * i] = !hit ? 0.0f : h.type == 0 ? h.u : h2f(h.uv[0]);
+			uv[2 * i + 1] = !hit ? 0.0f : h.type == 0 ? h.v : h2f(h.uv[1]);
+		}
 		if (steps) steps[i] = (uint32_t) cn.steps;
 		if (tests) tests[i] = (uint32_t) cn.tests;
 	}

@@ -53,7 +53,8 @@ typedef struct oracle_counters {
 
 /* intersect() of framebuffer.comp:423-456 for a batch of rays (AoS xyz).
  * kind: 0 miss, 1 triangle, 2 sphere.  prim: full 32-bit index.  t_h: fp16 bits.
- * uv (2 floats per ray, may be NULL): Moller-Trumbore u,v of the accepted hit.
+ * uv (2 floats per ray, may be NULL): Moller-Trumbore u,v of the accepted triangle; for a sphere hit HitData.uvs as the
+ * shader leaves them (fc:447-451 does not write uvs: the last accepted triangle's, else 0), widened to float.
  * steps/tests (may be NULL): per-ray S and T. */
 int oracle_trace_closest(const oracle_scene *sc, const float *ro, const float *rd, uint32_t n,
                          uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv,

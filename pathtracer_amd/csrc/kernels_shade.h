@@ -95,7 +95,7 @@ PT_DEV HitRec hit_attributes(const DevScene &sc, uint32_t prim, uint32_t tk, flo
 		h.uvx = q16(q16(q16(w * (float) h_from_bits(p0 & 0xffffu)) + q16(uh * (float) h_from_bits(p1 & 0xffffu))) +
 		            q16(vh * (float) h_from_bits(p2 & 0xffffu)));
 		h.uvy = q16(q16(q16(w * (float) h_from_bits(p0 >> 16)) + q16(uh * (float) h_from_bits(p1 >> 16))) +
-		            q16(vh * (float) h_from_bits(p2 >> 16)));
+		            q16(vh * (float) h_from_bits(p2 >> 16))); // the same expression as tri_uv_bits (kernels_trace.h)
 		const v3 sn = normalize(cross(e1, e2));
 		const v3 wn0 = V(q16(w * n0.x), q16(w * n0.y), q16(w * n0.z));
 		const v3 nn = normalize((wn0 + u * n1) + v * n2);
@@ -108,6 +108,10 @@ PT_DEV HitRec hit_attributes(const DevScene &sc, uint32_t prim, uint32_t tk, flo
 		h.mat = sm.x & 0xffu;
 		h.obj16 = prim & 0xffffu;
 		h.type = 1;
+		// fc:447-451 does not write result.uvs: they are still those of the last triangle the BVH pass accepted, which
+		// k_trace's flush put into the record's third word (tri_uv_bits; +0 when no triangle was accepted)
+		h.uvx = (float) h_from_bits(__float_as_uint(u) & 0xffffu);
+		h.uvy = (float) h_from_bits(__float_as_uint(u) >> 16);
 	}
 	return h;
 }

@@ -150,7 +150,8 @@ struct DevCtl {
 
 // One segment of rays.  Rays are structure-of-arrays with a common stride: ray[c*stride + i], c = 0..5 = ro.xyz,
 // rd.xyz (wave refills read runs of consecutive slots: coalesced).  A hit is ONE 16-byte record per slot,
-// hit[i] = (prim, t_h | kind<<16, u, v): lanes finish at different times, so a hit is written by a lone lane and
+// hit[i] = (prim, t_h | kind<<16, u, v) for a triangle (kind 1), (sphere, t_h | 2<<16, HitData.uvs as 2 x fp16 bits, 0)
+// for a sphere: lanes finish at different times, so a hit is written by a lone lane and
 // one dwordx4 store touches one 32-byte sector where four column stores touched four.
 struct RaySeg {
 	const float *ray;
@@ -215,6 +216,22 @@ PT_DEV float sphere_t(v3 ro, v3 rd, float4 s)
 }
 
 #define PT_CUR_DONE 0xffffffffu
+
+// data.uvs of an accepted triangle hit (fc:303-306: float16_t arithmetic, left to right), as the two fp16 bit patterns
+// uvx | uvy << 16.  One function for the shading kernels (every triangle hit) and for k_trace's flush (a sphere that wins
+// over an accepted triangle: fc:447-451 writes t, normal, mat_index, object_index and object_type but NOT uvs, so the
+// sphere's material is textured with the uvs of the last triangle intersect_bvh_stack accepted).
+PT_DEV uint32_t tri_uv_bits(const DevScene &sc, uint32_t prim, float u, float v)
+{
+	const float4 *tp = sc.tris + 4u * (size_t) prim;
+	const uint32_t p0 = __float_as_uint(tp[0].w), p1 = __float_as_uint(tp[1].w), p2 = __float_as_uint(tp[2].w);
+	const float w = q16((1.0f - u) - v), uh = q16(u), vh = q16(v);
+	const h16 ux = to_h16(q16(q16(w * (float) h_from_bits(p0 & 0xffffu)) + q16(uh * (float) h_from_bits(p1 & 0xffffu))) +
+	                      q16(vh * (float) h_from_bits(p2 & 0xffffu)));
+	const h16 uy = to_h16(q16(q16(w * (float) h_from_bits(p0 >> 16)) + q16(uh * (float) h_from_bits(p1 >> 16))) +
+	                      q16(vh * (float) h_from_bits(p2 >> 16)));
+	return h_bits(ux) | (h_bits(uy) << 16);
+}
 
 // Shadow rays (fc:970-974) are judged by the shading kernel from the CLOSEST hit: the light sample is visible iff
 // every component of y_nee - (ro + rd * t_hit) is < 0.01 (one-sided).
@@ -398,7 +415,13 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	// three lanes of a wave finish per iteration.
 	auto flush_finished = [&]() {
 		if (hitp && !is_active()) {
-			if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) { best_prim = sph_prim; best_tk = sph_tk; }
+			if (sph_tk != 0u && (float) h_from_bits(sph_tk & 0xffffu) <= tmax) {
+				// fc:447-451 leaves result.uvs alone: a sphere's record carries the uvs of the last accepted triangle (+0 when
+				// there was none: the oracle's zeroed `out` record) where a triangle's carries the barycentrics
+				best_u = __uint_as_float(best_tk != 0u ? tri_uv_bits(a.sc, best_prim, best_u, best_v) : 0u);
+				best_v = 0.0f;
+				best_prim = sph_prim; best_tk = sph_tk;
+			}
 			pt_u32x4 rec;
 			rec.x = best_prim; rec.y = best_tk; rec.z = __float_as_uint(best_u); rec.w = __float_as_uint(best_v);
 			PT_NT_STORE(rec, (pt_u32x4 *) hitp);

@@ -937,7 +937,10 @@ int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, ui
 		if (uv) {
 			memcpy(&uv[2 * (size_t) i], &h[2], 4);
 			memcpy(&uv[2 * (size_t) i + 1], &h[3], 4);
-			if (kind[i] != 1) uv[2 * (size_t) i] = uv[2 * (size_t) i + 1] = 0.0f;
+			if (kind[i] == 2) { // a sphere's record holds HitData.uvs (2 x fp16 bits, kept from the last accepted triangle) in its third word
+				uv[2 * (size_t) i] = (float) __builtin_bit_cast(_Float16, (uint16_t) (h[2] & 0xffffu));
+				uv[2 * (size_t) i + 1] = (float) __builtin_bit_cast(_Float16, (uint16_t) (h[2] >> 16));
+			} else if (kind[i] != 1) uv[2 * (size_t) i] = uv[2 * (size_t) i + 1] = 0.0f;
 		}
 	}
 	return PT_OK;

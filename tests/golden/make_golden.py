@@ -31,6 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as ol  # noqa: E402
 import pathtracer_amd as pt  # noqa: E402
+import scene_textured_spheres as sts  # noqa: E402
 from golden_inputs import fat_triangles, digest64, lcg_mesh, materials_in, spheres_in  # noqa: E402
 
 P = ctypes.c_void_p
@@ -133,7 +134,7 @@ def main():
     # ---- oracle: closest-hit batches
     tr = {}
     for name, sc in (("cornell_spheres", pt.Scene.cornell(spheres=True)), ("soup3000", pt.Scene.soup(3000, seed=5)),
-                     ("bunny12", pt.Scene.bunny(freq=12, target_tris=0, spheres=True))):
+                     ("bunny12", pt.Scene.bunny(freq=12, target_tris=0, spheres=True)), ("textured_spheres", sts.build(pt)[0])):
         ro, rd = golden_rays(4096, seed=len(name))
         prim, th, kind, uvv, steps, tests = ol.trace_closest(ol.scene_from_desc(sc.desc()), ro, rd, counts=True)
         tr[f"{name}_hash"] = np.array([sc.hash()], np.uint64)
@@ -148,7 +149,8 @@ def main():
     cam = pt.default_camera()
     seeds = pt.frame_seeds(0, 4)
     for name, sc, env in golden_frame_scenes(pt):
-        img, cnt = ol.render(ol.scene_from_desc(sc.desc(), env_rgb8=env), cam, 64, 64, seeds, bounces=5)
+        tex = sts.build(pt)[1] if name == "textured_spheres" else None
+        img, cnt = ol.render(ol.scene_from_desc(sc.desc(), env_rgb8=env, tex_rgb8=tex), cam, 64, 64, seeds, bounces=5)
         fr[f"{name}_hash"] = np.array([sc.hash()], np.uint64)
         fr[f"{name}_rgba"] = img
         fr[f"{name}_counts"] = np.array([cnt[k] for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce", "node_steps", "tri_tests")], np.uint64)
@@ -178,7 +180,8 @@ def golden_frame_scenes(pt):
     return [("cornell", pt.Scene.cornell(), None),
             ("cornell_spheres", pt.Scene.cornell(spheres=True), None),
             ("bunny12_on", pt.Scene.bunny(freq=12, target_tris=0), None),
-            ("bunny12_ggx_env", pt.Scene.bunny(freq=12, target_tris=0, material=pt.MAT_SPECULAR_METAL, roughness=0.2, spheres=True), golden_env())]
+            ("bunny12_ggx_env", pt.Scene.bunny(freq=12, target_tris=0, material=pt.MAT_SPECULAR_METAL, roughness=0.2, spheres=True), golden_env()),
+            ("textured_spheres", sts.build(pt)[0], None)]
 
 
 if __name__ == "__main__":

@@ -3,12 +3,12 @@ oracle with, so GPU == golden == oracle without the oracle having to run on the 
 import numpy as np
 import pytest
 
-from test_oracle import _scene, golden_env
+from test_oracle import _scene, golden_env, golden_tex
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["cornell_spheres", "soup3000", "bunny12"])
+@pytest.mark.parametrize("name", ["cornell_spheres", "soup3000", "bunny12", "textured_spheres"])
 def test_trace_golden(pt, golden, name):
     g = golden("oracle_trace.npz")
     sc = _scene(pt, name)
@@ -25,7 +25,7 @@ def test_trace_golden(pt, golden, name):
     assert np.array_equal(uv.view(np.uint32), g[f"{name}_uv"].view(np.uint32))
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_spheres", "bunny12_on", "bunny12_ggx_env"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_spheres", "bunny12_on", "bunny12_ggx_env", "textured_spheres"])
 def test_frame_golden(pt, golden, name):
     g = golden("oracle_frames.npz")
     sc = _scene(pt, name)
@@ -33,7 +33,7 @@ def test_frame_golden(pt, golden, name):
     env = golden_env() if name.endswith("_env") else None
     c = pt.PathTracer(64, 64, flags=pt.PT_FLAG_TRACE_DEAD_PATHS | pt.PT_FLAG_COUNT_TRAVERSAL | pt.PT_FLAG_SHADOW_FULL_TRAVERSAL)
     try:
-        c.upload_scene(sc, env_rgb8=env)
+        c.upload_scene(sc, env_rgb8=env, tex_rgb8=golden_tex(pt, name))
         c.set_camera(pt.default_camera())
         c.render(0, pt.frame_seeds(0, 4), 5)
         img = c.read_framebuffer()

@@ -3,13 +3,20 @@ golden vectors, independent re-computations of its primitives, and properties of
 import numpy as np
 import pytest
 
+import scene_textured_spheres as sts
+
 
 def _scene(pt, name):
-    return {"cornell": lambda: pt.Scene.cornell(), "cornell_spheres": lambda: pt.Scene.cornell(spheres=True),
+    return {"textured_spheres": lambda: sts.build(pt)[0],  # textured sphere materials in front of triangles with uvs (fc:447-451)
+            "cornell": lambda: pt.Scene.cornell(), "cornell_spheres": lambda: pt.Scene.cornell(spheres=True),
             "soup3000": lambda: pt.Scene.soup(3000, seed=5),
             "bunny12": lambda: pt.Scene.bunny(freq=12, target_tris=0, spheres=True),
             "bunny12_on": lambda: pt.Scene.bunny(freq=12, target_tris=0),
             "bunny12_ggx_env": lambda: pt.Scene.bunny(freq=12, target_tris=0, material=pt.MAT_SPECULAR_METAL, roughness=0.2, spheres=True)}[name]()
+
+
+def golden_tex(pt, name):
+    return sts.build(pt)[1] if name == "textured_spheres" else None
 
 
 def golden_env():
@@ -80,7 +87,7 @@ def test_minmax_are_minnum_maxnum(ol):
 
 
 # ------------------------------------------------------------------ golden vectors
-@pytest.mark.parametrize("name", ["cornell_spheres", "soup3000", "bunny12"])
+@pytest.mark.parametrize("name", ["cornell_spheres", "soup3000", "bunny12", "textured_spheres"])
 def test_trace_golden(pt, ol, golden, name):
     g = golden("oracle_trace.npz")
     sc = _scene(pt, name)
@@ -137,13 +144,13 @@ def test_trace_against_brute_force(pt, ol):
     assert checked > n // 2
 
 
-@pytest.mark.parametrize("name", ["cornell", "cornell_spheres", "bunny12_on", "bunny12_ggx_env"])
+@pytest.mark.parametrize("name", ["cornell", "cornell_spheres", "bunny12_on", "bunny12_ggx_env", "textured_spheres"])
 def test_frame_golden(pt, ol, golden, name):
     g = golden("oracle_frames.npz")
     sc = _scene(pt, name)
     assert sc.hash() == int(g[f"{name}_hash"][0]), "procedural scene changed: regenerate tests/golden"
     env = golden_env() if name.endswith("_env") else None
-    img, cnt = ol.render(ol.scene_from_desc(sc.desc(), env_rgb8=env), pt.default_camera(), 64, 64, pt.frame_seeds(0, 4), bounces=5)
+    img, cnt = ol.render(ol.scene_from_desc(sc.desc(), env_rgb8=env, tex_rgb8=golden_tex(pt, name)), pt.default_camera(), 64, 64, pt.frame_seeds(0, 4), bounces=5)
     assert np.array_equal(img.view(np.uint32), g[f"{name}_rgba"].view(np.uint32))
     assert [cnt[k] for k in ("paths", "rays_primary", "rays_shadow", "rays_bounce", "node_steps", "tri_tests")] == g[f"{name}_counts"].tolist()
     assert np.isfinite(img).all() and (img[..., 3] == 1.0).all()

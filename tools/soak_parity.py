@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import pathtracer_amd as pt
 import oracle_lib as ol
+import scene_textured_spheres as sts
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -34,7 +35,7 @@ def camera():
 
 
 def scene():
-    k = rng.integers(0, 5)
+    k = rng.integers(0, 6)
     tex = None
     if k == 0:
         sc, name = pt.Scene.cornell(spheres=bool(rng.integers(0, 2))), "cornell"
@@ -47,9 +48,16 @@ def scene():
         sc = pt.Scene.bunny(freq=int(rng.integers(3, 20)), target_tris=0, seed=int(rng.integers(1, 1 << 30)), material=mat, roughness=rough,
                             spheres=bool(rng.integers(0, 2)))
         name = f"bunny(m{mat},r{rough})"
-    else:
+    elif k == 4:
         sc, name = pt.Scene.atrium(detail=1, seed=int(rng.integers(1, 1 << 30))), "atrium"
         tex = pt.make_textures(6, int(rng.integers(1, 100)))
+    else:
+        # spheres with TEXTURED materials in front of triangles with uvs: a sphere hit keeps the last accepted triangle's uvs (fc:447-451)
+        extra = [((rng.uniform(-1.6, 1.6), rng.uniform(-1.6, 1.6), rng.uniform(-7.6, -4.4)), rng.uniform(0.05, 0.6),
+                  int(rng.choice([pt.MAT_LAMBERTIAN, pt.MAT_OREN_NAYAR, pt.MAT_SPECULAR_METAL])), float(rng.choice([0.0, 0.05, 0.2, 0.6])),
+                  int(rng.integers(-1, 3))) for _ in range(int(rng.integers(0, 6)))]
+        sc, tex = sts.build(pt, wall_uv_shift=float(rng.uniform(-2, 2)), extra=extra)
+        name = f"textured_spheres(+{len(extra)})"
     return sc, tex, name
 
 
