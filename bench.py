@@ -65,19 +65,26 @@ def make_scene(pt, name):
     raise SystemExit(f"unknown scene {name}")
 
 
-def pmc_profile(workload_key):
+def pmc_profile(workload_key, kernel_sha):
     """Per-launch PMC figures of k_trace from the committed rocprofv3 --pmc passes of this same workload
-    (profiles/*_pmc_traffic.json, written by tools/prof_summary.py): bench.py cannot run the profiler on itself."""
+    (profiles/*_pmc_traffic.json, written by tools/prof_summary.py): bench.py cannot run the profiler on itself.
+    Only a profile stamped with the SHA-256 of the device sources this run executes counts (`kernel_sha256`, written by
+    tools/prof_summary.py): returns (profile or None, reason when None)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+    stale = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") == workload_key and "k_trace" in d.get("kernels", {}):
-            best = d
-    return best
+            if d.get("kernel_sha256") == kernel_sha:
+                return d, None
+            stale = stale or os.path.basename(f)
+    if stale:
+        return None, (f"no PMC profile of the kernel sources this run executes (sha256 {kernel_sha[:12]}...): the newest one for this workload, "
+                      f"profiles/{stale}, was taken on other sources -- re-run tools/prof.sh and commit its summary")
+    return None, f"no PMC profile for workload {workload_key} under profiles/"
 
 
 def gather_ceiling(device, miss_l1, miss_l2, active_lanes, waves_per_simd):
@@ -133,8 +140,12 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=48)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; what the driver runs) or gloo (rehearsal of the N > 1 "
                     "code path with several ranks sharing one GPU: the exchange then goes through host memory)")
-    ap.add_argument("--check", action="store_true", help="N > 1: compare the exchanged image with a sequential render of the same "
-                    "frames on rank 0 (tiles: bit-identical; samples: 2e-6 relative)")
+    ap.add_argument("--check", action="store_true", help="kept for old command lines: at N > 1 the check now always runs (see --no-check)")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the comparison of the exchanged image with a sequential render of the "
+                    "same frames on rank 0 (tiles: bit-identical; samples: 2e-6 relative); it runs once, outside the timed regions")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of back-to-back K-step regions after the timed ones (0 = off): "
+                    "`sustained_ms_per_step` is long enough to be confirmed by an outside clock")
+    ap.add_argument("--no-anyhit", action="store_true", help="skip the PT_FLAG_SHADOW_ANYHIT leg (rate + image RMSE against the default mode)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -272,6 +283,33 @@ def main():
     dt, cnt = regions[order[len(order) // 2]]
     rays = cnt["rays_primary"] + cnt["rays_shadow"] + cnt["rays_bounce"]
 
+    # ---- sustained leg: the same K-step region back to back until at least --sustain seconds have passed, so that the time
+    # per step can be confirmed from outside the process (the driver's wall clock, GPU-busy samples): 3 x K steps are a few
+    # tens of milliseconds.  Whole regions only; timed like the regions above; reported beside the median, never instead of it.
+    sustained = None
+    if args.sustain > 0:
+        sync_all()
+        s0 = time.perf_counter()
+        n_reg = 0
+        while True:
+            ctx.render(0, timed, args.bounces)
+            if dist is not None:
+                exchange(K, K * (1 if tiles else world))
+            n_reg += 1
+            ctx.sync()
+            el = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+            if dist is not None:
+                dist.all_reduce(el, op=dist.ReduceOp.MAX)  # every rank takes the same decision
+            if float(el.item()) >= args.sustain or n_reg >= 100000:
+                break
+        sync_all()
+        sdt = time.perf_counter() - s0
+        if dist is not None:
+            tmax = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            sdt = float(tmax.item())
+        sustained = {"seconds": round(sdt, 3), "regions": n_reg, "steps": n_reg * K, "ms_per_step": round(sdt / (n_reg * K) * 1e3, 4)}
+
     if dist is not None:
         tot = torch.tensor([rays, cnt["paths"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -279,8 +317,17 @@ def main():
     else:
         rays_total, paths_total = rays, cnt["paths"]
 
+    # ---- N > 1: who took part, and did N ranks on N devices produce the right image?  Outside the timed regions.
+    ranks_seen = None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "device": torch.cuda.get_device_name(local_rank),
+              "pci_bus_id": "%04x:%02x:%02x" % (int(getattr(props, "pci_domain_id", 0)), int(getattr(props, "pci_bus_id", 0)), int(getattr(props, "pci_device_id", 0))),
+              "uuid": str(getattr(props, "uuid", "")), "backend": args.dist_backend}
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
     check = None
-    if dist is not None and args.check and rank == 0:
+    if dist is not None and not args.no_check and rank == 0:
         got = (full_ctx if tiles else ctx).read_framebuffer()
         sctx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags, max_batch=args.max_batch)
         sctx.upload_scene(scene, tex_rgb8=tex, tex_sampler=tex_sampler)
@@ -323,7 +370,8 @@ def main():
     rays_per_launch = rays / launches
     sec = avg_launch_ms * 1e-3
     workload_key = f"{args.scene}-{args.width}x{args.height}-b{args.bounces}" + ("" if args.bvh == "reference" else f"-{args.bvh}")
-    pmc = pmc_profile(workload_key)
+    kernel_sha = pt.kernel_source_sha256()
+    pmc, pmc_missing = pmc_profile(workload_key, kernel_sha)
     kern = (pmc or {}).get("kernels", {})
     pk = kern.get("k_trace_all") or kern.get("k_trace", {})  # all trace launches of a batch, like the HIP-event average here
     traffic = None
@@ -371,6 +419,11 @@ def main():
                                f"instruction count: SQ_INSTS_VALU per ray of {pmc_name}",
                 "valu_insts_per_launch": round(insts),
                 "valu_lane_utilisation": round(pk["sq_thread_cycles_valu"] / (64.0 * pk["sq_active_inst_valu"]), 4) if pk.get("sq_active_inst_valu") else None}
+        if valu["valu_lane_utilisation"] is not None:
+            # issue slots that did work for a ray: the kernel issues `frac` of the peak's wave-instructions, and of the 64 lanes of
+            # an issued instruction only this share is switched on (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU)
+            valu["valu_useful_frac"] = round(valu["frac"] * valu["valu_lane_utilisation"], 4)
+            valu["peak_source"] += "; valu_useful_frac = frac x valu_lane_utilisation = the share of the peak's LANE-slots that carry a ray's arithmetic"
     # (2) SURVEY.md 8(d)'s figure, kept for the record: algorithmic bytes against the HBM peak.  The 7 MB blob is
     # cache-served, so this "fraction" exceeds 1 and is NOT the binding roof; hbm_counter_frac is the HBM-side truth.
     bytes_per_ray = 64.0 * S + 64.0 * T + 96.0
@@ -390,6 +443,12 @@ def main():
                 "node_steps_per_ray": round(S, 3), "tri_tests_per_ray": round(T, 3),
                 "rays_per_launch": round(rays_per_launch, 1), "avg_launch_ms": round(avg_launch_ms, 4),
                 "trace_ms_total": round(cnt["ms_trace"], 3), "shade_ms_total": round(cnt["ms_shade"], 3)})
+    roofline["kernel_sha256"] = kernel_sha
+    if pmc is None:
+        # the instruction counts and cache-miss rates that price the roofline come from PMC passes; without passes of THESE sources
+        # there is no fraction to report (the live figures below -- S, T, launch time, algorithmic bytes -- stand)
+        roofline.update({"bound": "valu-issue", "achieved": None, "peak": round(valu_peak, 2), "unit": "G wave-instr/s", "frac": None,
+                         "frac_withheld": pmc_missing, "second_resource": vmem})
     # the other third of the frame: k_shade (+ its primary form and k_resolve) IS bound by HBM bytes -- PMC bytes per launch of the same
     # workload over the HIP-event time of these kernels in the timed region
     if have_pmc and all(k in pmc["kernels"] for k in ("k_shade", "k_shade<primary>", "k_resolve")) and cnt["ms_shade"] > 0:
@@ -417,6 +476,40 @@ def main():
                "sample": f"{nf} frame(s) of the same {args.width}x{args.height} workload (the oracle traces zero-throughput paths too)",
                "spp_per_s": round(nf / cdt, 4), "seconds": round(cdt, 2)}
 
+    # ---- the fast shadow mode (hard part 2): the headline number is the reference's closest-hit shadow semantics
+    # (fc:970-974); PT_FLAG_SHADOW_ANYHIT stops a shadow ray at ANY hit in front of the light sample.  Its rate, and how far its
+    # image is from the default mode's on the SAME frames, stated beside the headline -- never as the headline.
+    anyhit = None
+    if world == 1 and not args.no_anyhit:
+        base_img = ctx.read_framebuffer()  # the K timed frames in the default mode (every region renders the same frames)
+        actx = pt.PathTracer(args.width, args.height, device=local_rank, flags=flags | pt.PT_FLAG_SHADOW_ANYHIT, max_batch=args.max_batch)
+        actx.upload_scene(scene, tex_rgb8=tex, tex_sampler=tex_sampler)
+        actx.set_camera(cam)
+        actx.render(0, timed[: min(actx.max_batch, K)], args.bounces)  # warm-up: one launch set of the timed size
+        adts = []
+        for _ in range(max(1, args.repeats)):
+            actx.clear_framebuffer()
+            actx.reset_counters()
+            actx.sync()
+            a0 = time.perf_counter()
+            actx.render(0, timed, args.bounces)
+            actx.sync()
+            adts.append(time.perf_counter() - a0)
+        acnt = actx.counters()
+        any_img = actx.read_framebuffer()
+        actx.close()
+        adt = sorted(adts)[len(adts) // 2]
+        arays = acnt["rays_primary"] + acnt["rays_shadow"] + acnt["rays_bounce"]
+        mean = float(base_img[..., :3].mean())
+        rmse = float(np.sqrt(np.mean((any_img[..., :3].astype(np.float64) - base_img[..., :3].astype(np.float64)) ** 2)))
+        anyhit = {"flag": "PT_FLAG_SHADOW_ANYHIT", "value": round(arays / adt / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(adt / K * 1e3, 4),
+                  "vs_closest_hit_mode": round((arays / adt) / (rays_total / dt), 4),
+                  "image_rmse_vs_default": rmse, "image_rmse_rel_to_mean_radiance": round(rmse / mean, 6) if mean > 0 else None,
+                  "mean_radiance_default": mean, "mean_radiance_anyhit": float(any_img[..., :3].mean()),
+                  "differing_pixels": int((any_img.view(np.uint32) != base_img.view(np.uint32)).any(axis=2).sum()),
+                  "frames_compared": K, "rays": arays,
+                  "note": "same frames and seeds in both modes; any-hit ignores the one-sided compare of fc:974, so it can only remove light"}
+
     spp_total = K * (1 if (tiles or world == 1) else world)
     out = {
         "metric": f"Mrays/s (closest-hit + NEE shadow rays), MIS path, {'bunny-class' if args.scene.startswith('bunny') else os.path.basename(args.scene)} scene {args.width}x{args.height}",
@@ -436,8 +529,16 @@ def main():
         "setup": {"scene_generation_and_cpu_bvh_build_s": round(t_scene, 3), "upload_incl_traversal_blob_ms": round(t_upload * 1e3, 2),
                   "gpu_bvh_build_ms": round(t_gpu_bvh_ms, 3) if t_gpu_bvh_ms is not None else None},
     }
+    out["sustained_ms_per_step"] = sustained["ms_per_step"] if sustained else None
+    out["sustained"] = sustained
+    out["world_size"] = world
+    if ranks_seen is not None:
+        out["ranks_seen"] = ranks_seen
+        out["distinct_devices"] = len({(r["host"], r["pci_bus_id"], r["uuid"]) for r in ranks_seen})
     if check is not None:
         out["check"] = check
+    if anyhit is not None:
+        out["anyhit"] = anyhit
     print(json.dumps(out))
     sys.stdout.flush()
     ctx.close()

@@ -166,7 +166,10 @@ int pt_trace_closest_device(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void 
  * device array that every GPU the library runs on holds until the process ends, and the call makes no hipMalloc /
  * hipFree / event creation.  At most PT_NOALLOC_MAX_RAYS rays per call (PT_EINVAL beyond).  All calls on one GPU share
  * that GPU's array: calls that overlap on one GPU (any contexts, any streams) race; back-to-back calls on the
- * context's stream are fine.  Asynchronous like pt_trace_closest_device; not timed in pt_counters. */
+ * context's stream are fine.  Asynchronous like pt_trace_closest_device; not timed in pt_counters.  It never synchronises:
+ * with renders of this context still in flight it returns PT_ESTATE (call pt_sync first).  Its grid is capped at 2,048 waves
+ * (a quarter of pt_create's grid on a 256-CU part -- what the 26 MiB spill tail is sized for): measured 0.83 x the rate of
+ * pt_trace_closest_device on 4 M incoherent rays (6.3 against 7.7 Grays/s, tests/test_zz_no_alloc.py prints it). */
 #define PT_NOALLOC_MAX_RAYS (1u << 26)
 int pt_trace_closest_device_noalloc(pt_ctx *ctx, const void *ray6_dev, uint32_t n, void *hit4_dev);
 
@@ -200,7 +203,9 @@ int pt_unpack_from(pt_ctx *ctx, const void *src_dev, uint32_t from_rank, uint32_
 typedef struct pt_group pt_group;
 int pt_group_create(const pt_config *cfg, const int32_t *devices, uint32_t n_devices, uint32_t mode, pt_group **out);
 int pt_group_destroy(pt_group *g);
-const char *pt_group_last_error(const pt_group *g); /* g may be NULL: error of the last failed pt_group_create */
+const char *pt_group_last_error(const pt_group *g); /* g may be NULL: error of the last failed pt_group_create.  Right after a SUCCESSFUL
+                                                       pt_group_create the text is empty, or names the device pairs whose peer access
+                                                       could not be enabled (their gathers then run on staged copies: slower, same result) */
 uint32_t pt_group_size(const pt_group *g);
 pt_ctx *pt_group_member(pt_group *g, uint32_t i);   /* the member's own context, e.g. for pt_get_counters per device */
 int pt_group_upload_scene(pt_group *g, const pt_scene_desc *scene);

@@ -955,8 +955,8 @@ v3 estimator_path_tracing_nee(Ctx &cx, v3 ro, v3 rd, uint32_t rng_state, uint32_
 	return color;
 }
 
-// fc:1088-1112
-v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int py, uint32_t rng_state, uint32_t bounces, uint32_t flags)
+// fc:1088-1107: the jittered pinhole ray of pixel (px, py); two draws, x first
+void primary_ray(const float cam[12], float sw, float sh, int px, int py, uint32_t &rng_state, v3 *ro, v3 *rd)
 {
 	v3 cam_origin = V(cam[0], cam[1], cam[2]);
 	v3 cam_forward = V(cam[4], cam[5], cam[6]);
@@ -973,7 +973,15 @@ v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int
 	float u = ((float) px + ox) / sw;
 	float v = ((float) py + oy) / sh;
 	v3 point_on_grid = (grid_origin + u * grid_x) + v * grid_y;
-	v3 ray_direction = normalize(point_on_grid - cam_origin);
+	*ro = cam_origin;
+	*rd = normalize(point_on_grid - cam_origin);
+}
+
+// fc:1088-1112
+v3 render_function(Ctx &cx, const float cam[12], float sw, float sh, int px, int py, uint32_t rng_state, uint32_t bounces, uint32_t flags)
+{
+	v3 cam_origin, ray_direction;
+	primary_ray(cam, sw, sh, px, py, rng_state, &cam_origin, &ray_direction);
 	// fc:1109-1111: the reference picks the estimator by (un)commenting one of these three lines
 	if (flags & ORACLE_FLAG_EST_BRDF) return estimator_path_tracing_BRDF(cx, cam_origin, ray_direction, rng_state, bounces);
 	if (flags & ORACLE_FLAG_EST_NEE) return estimator_path_tracing_nee(cx, cam_origin, ray_direction, rng_state, bounces);
@@ -1173,6 +1181,16 @@ int oracle_probe(int what, const float *in, uint32_t n, float *out, uint32_t fla
 			m3 m; m.r0 = V(a[0], a[1], a[2]); m.r1 = V(a[3], a[4], a[5]); m.r2 = V(a[6], a[7], a[8]);
 			m3 r = inverse(m);
 			put(out + 9 * (size_t) i, r.r0); put(out + 9 * (size_t) i + 3, r.r1); put(out + 9 * (size_t) i + 6, r.r2);
+			break;
+		}
+		case ORACLE_PROBE_PRIMARY_RAY: {
+			const float *a = in + 17 * (size_t) i;
+			uint32_t rng_state = seed3((uint32_t) (int) a[14], (uint32_t) (int) a[15], fbits(a[16])); // fc:1120
+			v3 ro, rd;
+			primary_ray(a, a[12], a[13], (int) a[14], (int) a[15], rng_state, &ro, &rd);
+			float *o = out + 7 * (size_t) i;
+			put(o, ro); put(o + 3, rd);
+			memcpy(o + 6, &rng_state, 4);
 			break;
 		}
 		default: return -1;

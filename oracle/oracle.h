@@ -91,7 +91,8 @@ enum {
 	ORACLE_PROBE_PICK_WI = 5,            /* fc:563-589  in (rng bits, wo.xyz, type, roughness)  out wi, wm, cos, pdf             6 -> 8 */
 	ORACLE_PROBE_CALC_BRDF = 6,          /* fc:591-643  in (wo, wm, wi, diffuse rgb, F0 rgb, type, roughness, using_NEE)  out rgb 18 -> 3 */
 	ORACLE_PROBE_OCT_DECODE = 7,         /* fc:203-210  in (packed 2x fp16 as float bits)  out the f16vec3 normal widened        1 -> 3 */
-	ORACLE_PROBE_INVERSE3 = 8            /* inverse(mat3), fc:908  in 9 (rows)          out 9 (rows)                             9 -> 9 */
+	ORACLE_PROBE_INVERSE3 = 8,           /* inverse(mat3), fc:908  in 9 (rows)          out 9 (rows)                             9 -> 9 */
+	ORACLE_PROBE_PRIMARY_RAY = 9         /* fc:1088-1107,1120  in (camera 12, W, H, px, py, frame seed as float bits)  out ro, rd, rng state bits after the jitter draws  17 -> 7 */
 };
 int oracle_probe(int what, const float *in, uint32_t n, float *out, uint32_t flags);
 

@@ -13,7 +13,7 @@ from ctypes import POINTER, byref, c_char_p, c_double, c_float, c_int, c_int32, 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpt355.so")
+LIB_PATH = os.environ.get("PT355_LIB") or os.path.join(_HERE, "libpt355.so")  # PT355_LIB: an A/B build of the same library (tools/exp_build.sh)
 
 PT_FLAG_SHADOW_ANYHIT = 1
 PT_FLAG_TRACE_DEAD_PATHS = 2
@@ -150,6 +150,20 @@ EXPORTS = {
 }
 
 _lib = None
+
+KERNEL_SOURCES = ("device_math.h", "kernels_trace.h", "kernels_shade.h")
+
+
+def kernel_source_sha256() -> str:
+    """SHA-256 over the device code of the hot path (csrc/device_math.h, kernels_trace.h, kernels_shade.h, in that order).
+    tools/prof_summary.py stamps every profiles/*_pmc_traffic.json with it and bench.py refuses to price a roofline with PMC
+    figures whose stamp is not that of the sources it runs: a profile of another kernel is not evidence for this one."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def lib():

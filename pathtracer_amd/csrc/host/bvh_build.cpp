@@ -85,6 +85,7 @@ struct Builder {
 	std::vector<uint8_t> goes_left;
 	std::vector<uint32_t> scratch;
 	std::vector<RawNode> nodes;
+	bool failed = false;
 
 	static constexpr size_t kMaxDepth = 64;    // top_down_builder.hpp:36
 	static constexpr size_t kMaxLeaf = 16;     // top_down_builder.hpp:41
@@ -166,6 +167,11 @@ struct Builder {
 		for (size_t i = cut; i < r.end; ++i) hi_box.grow(prim_box[ord[i]]);
 
 		const size_t child = nodes.size();
+		// A binary tree over n primitives has at most 2n - 1 nodes, and the caller's array holds 2n + 1 (the library allocates the
+		// same, bvh.hpp / sweep_sah_builder.hpp:61).  Only non-finite input gets here with more: with NaN costs no split position
+		// wins, the "split" keeps the whole range on one side, and the range recurses to max_depth.  The reference writes past
+		// its array then; this builder reports failure.
+		if (child + 2 > 2 * n + 1) { failed = true; return false; }
 		nodes.resize(child + 2);
 		RawNode &self = nodes[r.node]; // resize may have moved the array
 		self.first = (uint32_t) child;
@@ -226,7 +232,7 @@ struct Builder {
 			const Range r = todo.back();
 			todo.pop_back();
 			Range a, b;
-			if (!split(r, &a, &b)) continue;
+			if (!split(r, &a, &b)) { if (failed) return; continue; }
 			if (a.size() > b.size()) std::swap(a, b);
 			todo.push_back(b); // larger half waits; smaller half is expanded (and numbered) first
 			todo.push_back(a);
@@ -242,6 +248,7 @@ extern "C" uint32_t pth_build_bvh(const void *tris_in, uint32_t n, void *nodes_o
 	const PtTriangle *tris = (const PtTriangle *) tris_in;
 	Builder b;
 	b.run(tris, n);
+	if (b.failed) return 0; // non-finite vertices: no tree (see Builder::split)
 	PtNode *out = (PtNode *) nodes_out;
 	PtTriangle *sorted = (PtTriangle *) sorted_out;
 	for (size_t i = 0; i < b.nodes.size(); i++) {

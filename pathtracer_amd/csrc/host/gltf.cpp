@@ -69,10 +69,29 @@ struct JVal {
 		const JVal *v = get(key);
 		return v && v->type == Num ? v->num : dflt;
 	}
+	// A JSON number is a double, and a hostile file puts anything there: every conversion to an integer type checks the
+	// value BEFORE the cast (negative, huge or non-finite doubles cast straight to an integer are undefined behaviour).
+	static long to_index(double v) { return v >= 0.0 && v < 2147483648.0 ? (long) v : -1; }
 	long index(const char *key) const
 	{
 		const JVal *v = get(key);
-		return v && v->type == Num ? (long) v->num : -1;
+		return v && v->type == Num ? to_index(v->num) : -1;
+	}
+	// non-negative size / offset / count; false when the file holds something that is not one (then *out is untouched)
+	bool size(const char *key, size_t dflt, size_t *out) const
+	{
+		const JVal *v = get(key);
+		if (!v || v->type != Num) { *out = dflt; return true; }
+		if (!(v->num >= 0.0) || !(v->num <= 9007199254740992.0)) return false;
+		*out = (size_t) v->num;
+		return true;
+	}
+	// small integers (enums, modes): anything outside int's range reads as -1, which no caller accepts
+	int small(const char *key, int dflt) const
+	{
+		const JVal *v = get(key);
+		if (!v || v->type != Num) return dflt;
+		return v->num >= -2147483648.0 && v->num <= 2147483647.0 ? (int) v->num : -1;
 	}
 };
 
@@ -177,6 +196,14 @@ struct View { long buffer = -1; size_t offset = 0, size = 0, stride = 0; };
 enum AType { A_SCALAR, A_VEC2, A_VEC3, A_VEC4, A_OTHER };
 struct Accessor { long view = -1; size_t offset = 0, count = 0, stride = 0; int comp = 0; AType type = A_OTHER; };
 
+// do `count` (>= 1) elements of `need` bytes, `stride` apart from base + offset, all lie inside `len` bytes?  Overflow-free.
+bool span_inside(size_t base, size_t offset, size_t stride, size_t count, size_t need, size_t len)
+{
+	if (base > len || offset > len - base || need > len - base - offset) return false;
+	if (count == 1) return true;
+	if (stride == 0) return false; // more than one element in the same place: never a valid accessor
+	return (count - 1) <= (len - base - offset - need) / stride;
+}
 size_t comp_size(int c) { return c == 5120 || c == 5121 ? 1 : (c == 5122 || c == 5123 ? 2 : (c == 5125 || c == 5126 ? 4 : 0)); }
 size_t type_count(AType t) { return t == A_SCALAR ? 1 : (t == A_VEC2 ? 2 : (t == A_VEC3 ? 3 : (t == A_VEC4 ? 4 : 0))); }
 
@@ -249,7 +276,8 @@ int parse_document(const char *path, Doc &d)
 		for (size_t i = 0; i < bs->arr.size(); i++) {
 			Buffer b;
 			const JVal &jb = bs->arr[i];
-			const size_t want = (size_t) jb.number("byteLength", 0);
+			size_t want = 0;
+			if (!jb.size("byteLength", 0, &want)) return fail("LoadGLTF: buffer %zu: byteLength is not a size", i);
 			const JVal *uri = jb.get("uri");
 			if (!uri) {
 				if (i != 0 || !bin) return fail("LoadGLTF: buffer %zu has no uri and there is no GLB BIN chunk for it", i);
@@ -266,10 +294,11 @@ int parse_document(const char *path, Doc &d)
 		for (const JVal &jv : vs->arr) {
 			View v;
 			v.buffer = jv.index("buffer");
-			v.offset = (size_t) jv.number("byteOffset", 0);
-			v.size = (size_t) jv.number("byteLength", 0);
-			v.stride = (size_t) jv.number("byteStride", 0);
-			if (v.buffer < 0 || (size_t) v.buffer >= d.buffers.size() || v.offset + v.size > d.buffers[v.buffer].data.size())
+			if (!jv.size("byteOffset", 0, &v.offset) || !jv.size("byteLength", 0, &v.size) || !jv.size("byteStride", 0, &v.stride))
+				return fail("LoadGLTF: buffer view %zu: offset, length or stride is not a size", d.views.size());
+			// size <= len && offset <= len - size: the sum of two hostile sizes may wrap
+			if (v.buffer < 0 || (size_t) v.buffer >= d.buffers.size() || v.size > d.buffers[v.buffer].data.size() ||
+			    v.offset > d.buffers[v.buffer].data.size() - v.size)
 				return fail("LoadGLTF: buffer view %zu lies outside its buffer", d.views.size());
 			d.views.push_back(v);
 		}
@@ -277,9 +306,9 @@ int parse_document(const char *path, Doc &d)
 		for (const JVal &ja : as->arr) {
 			Accessor a;
 			a.view = ja.index("bufferView");
-			a.offset = (size_t) ja.number("byteOffset", 0);
-			a.count = (size_t) ja.number("count", 0);
-			a.comp = (int) ja.number("componentType", 0);
+			if (!ja.size("byteOffset", 0, &a.offset) || !ja.size("count", 0, &a.count))
+				return fail("LoadGLTF: accessor %zu: offset or count is not a size", d.accessors.size());
+			a.comp = ja.small("componentType", 0);
 			const JVal *t = ja.get("type");
 			const std::string ts = t ? t->str : "";
 			a.type = ts == "SCALAR" ? A_SCALAR : (ts == "VEC2" ? A_VEC2 : (ts == "VEC3" ? A_VEC3 : (ts == "VEC4" ? A_VEC4 : A_OTHER)));
@@ -749,10 +778,10 @@ int load_material(const Doc &d, const JVal *jm, pth_model *out, int *num_loaded_
 				const JVal *js = (smp >= 0 && smps && (size_t) smp < smps->arr.size()) ? &smps->arr[smp] : nullptr;
 				// loader.cpp:242-251: array-wide, so the LAST textured primitive's sampler wins; cgltf's defaults for absent
 				// keys are 0 filters and GL_REPEAT wraps; no sampler at all = GL_LINEAR / GL_REPEAT
-				out->min_filter = js ? (uint32_t) js->number("minFilter", 0) : 9729u;
-				out->mag_filter = js ? (uint32_t) js->number("magFilter", 0) : 9729u;
-				out->wrap_s = js ? (uint32_t) js->number("wrapS", 10497) : 10497u;
-				out->wrap_t = js ? (uint32_t) js->number("wrapT", 10497) : 10497u;
+				out->min_filter = js ? (uint32_t) js->small("minFilter", 0) : 9729u;
+				out->mag_filter = js ? (uint32_t) js->small("magFilter", 0) : 9729u;
+				out->wrap_s = js ? (uint32_t) js->small("wrapS", 10497) : 10497u;
+				out->wrap_t = js ? (uint32_t) js->small("wrapT", 10497) : 10497u;
 			}
 			for (int k = 0; k < 3; k++) diffuse[k] = base[k];
 			if (metallic < 0.0001f) { // loader.cpp:270-287 (EPSILON, src/math/math.hpp:11)
@@ -798,13 +827,13 @@ int pth_load_gltf(const char *path, pth_model *out)
 		const JVal *prims = meshes->arr[mi].get("primitives");
 		for (size_t pi = 0; prims && pi < prims->arr.size(); pi++) {
 			const JVal &prim = prims->arr[pi];
-			if ((int) prim.number("mode", 4) != 4) return fail("LoadGLTF: only triangles are supported as primitives (loader.cpp:73-79)");
+			if (prim.small("mode", 4) != 4) return fail("LoadGLTF: only triangles are supported as primitives (loader.cpp:73-79)");
 			// ---- attributes, in file order (loader.cpp:81-141)
 			if (const JVal *attrs = prim.get("attributes"))
 				for (const auto &kv : attrs->obj) {
 					const bool is_pos = kv.first == "POSITION", is_nrm = kv.first == "NORMAL", is_uv = kv.first.compare(0, 8, "TEXCOORD") == 0;
 					if (!is_pos && !is_nrm && !is_uv) continue;
-					const long ai = kv.second.type == JVal::Num ? (long) kv.second.num : -1;
+					const long ai = kv.second.type == JVal::Num ? JVal::to_index(kv.second.num) : -1;
 					if (ai < 0 || (size_t) ai >= d.accessors.size()) return fail("LoadGLTF: attribute %s names accessor %ld", kv.first.c_str(), ai);
 					const Accessor &a = d.accessors[ai];
 					if (a.view < 0) return fail("LoadGLTF: attribute %s has no buffer view", kv.first.c_str());
@@ -812,9 +841,12 @@ int pth_load_gltf(const char *path, pth_model *out)
 					const std::vector<uint8_t> &buf = d.buffers[view.buffer].data;
 					const size_t stride = view.stride != 0 ? view.stride : a.stride;
 					const size_t need = a.type == A_VEC3 ? 12 : (a.type == A_VEC2 ? 8 : 0);
+					// all `count` elements must lie inside the buffer, proven before the first is read: a stride of 0 (unknown component
+					// type) with a count of 1e18 would otherwise append the same element until memory runs out, and offset sums may wrap
+					if (need && a.count && !span_inside(view.offset, a.offset, stride, a.count, need, buf.size()))
+						return fail("LoadGLTF: attribute %s reads past its buffer", kv.first.c_str());
 					for (size_t i = 0; i < a.count && need; i++) {
 						const size_t at = view.offset + a.offset + stride * i;
-						if (at + need > buf.size()) return fail("LoadGLTF: attribute %s reads past its buffer", kv.first.c_str());
 						float f[3] = {0, 0, 0};
 						memcpy(f, buf.data() + at, need);
 						if (a.type == A_VEC3) {
@@ -837,9 +869,9 @@ int pth_load_gltf(const char *path, pth_model *out)
 				const View &view = d.views[a.view];
 				const std::vector<uint8_t> &buf = d.buffers[view.buffer].data;
 				const size_t stride = view.stride != 0 ? view.stride : a.stride;
+				if (a.count && !span_inside(view.offset, 0, stride, a.count, 2, buf.size())) return fail("LoadGLTF: indices read past their buffer");
 				for (size_t i = 0; i < a.count; i++) {
 					const size_t at = view.offset + stride * i; // NOT + accessor offset: loader.cpp:159
-					if (at + 2 > buf.size()) return fail("LoadGLTF: indices read past their buffer");
 					uint16_t val;
 					memcpy(&val, buf.data() + at, 2);
 					indices.push_back(val);
@@ -905,7 +937,9 @@ uint32_t pth_model_material_count(const pth_model *m) { return (uint32_t) m->mat
 
 int pth_model_get(const pth_model *m, float *v9, float *n9, float *uv6, uint32_t *mat, void *materials48)
 {
+	if (!m) return PT_EINVAL;
 	const size_t n = m->mat.size();
+	if (n == 0 && m->materials.empty()) return PT_OK; // nothing to copy: memcpy from an empty vector's null data() is undefined even for 0 bytes
 	if (v9) memcpy(v9, m->v.data(), n * 36);
 	if (n9) memcpy(n9, m->n.data(), n * 36);
 	if (uv6) memcpy(uv6, m->uv.data(), n * 24);
@@ -930,6 +964,7 @@ int pth_scene_add_model(pth_scene *s, const pth_model *m)
 	const uint32_t base = pth_scene_add_packed_materials(s, m->materials.data(), (uint32_t) m->materials.size());
 	std::vector<uint32_t> mat(m->mat);
 	for (uint32_t &x : mat) x += base;
+	if (mat.empty()) return PT_OK; // a file without meshes, or a model nothing was loaded into: materials only
 	return pth_scene_add_triangles(s, &m->v[0].x, &m->n[0].x, m->uv.data(), mat.data(), (uint32_t) mat.size());
 }
 

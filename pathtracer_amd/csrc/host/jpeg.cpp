@@ -193,9 +193,10 @@ bool decode_block(Jpeg &j, int16_t data[64], int c)
 	if (t < 0 || t > 15) return j.fail("bad huffman code");
 	memset(data, 0, 64 * sizeof(int16_t));
 	const int diff = t ? j.receive_extend(t) : 0;
-	const int dc = cp.dc_pred + diff;
+	// a crafted stream can run the predictor out of int: wrap (as unsigned) instead of overflowing; a valid file never gets near
+	const int dc = (int) ((uint32_t) cp.dc_pred + (uint32_t) diff);
 	cp.dc_pred = dc;
-	data[0] = (int16_t) (dc * dq[0]);
+	data[0] = (int16_t) ((uint32_t) dc * (uint32_t) dq[0]);
 	int k = 1;
 	do {
 		const int rs = j.decode(hac);
@@ -223,10 +224,10 @@ bool decode_block_prog_dc(Jpeg &j, int16_t data[64], int c)
 		const int t = j.decode(j.hdc[cp.hd]);
 		if (t < 0 || t > 15) return j.fail("can't merge dc and ac");
 		const int diff = t ? j.receive_extend(t) : 0;
-		const int dc = cp.dc_pred + diff;
+		const int dc = (int) ((uint32_t) cp.dc_pred + (uint32_t) diff); // wraps instead of overflowing on a crafted stream
 		cp.dc_pred = dc;
-		data[0] = (int16_t) (dc * (1 << j.succ_low));
-	} else if (j.getbit()) data[0] += (int16_t) (1 << j.succ_low);
+		data[0] = (int16_t) ((uint32_t) dc * (1u << j.succ_low));
+	} else if (j.getbit()) data[0] = (int16_t) ((uint32_t) (uint16_t) data[0] + (1u << j.succ_low));
 	return true;
 }
 

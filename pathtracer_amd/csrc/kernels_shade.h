@@ -688,7 +688,12 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 // at the head of stage b+1 (nothing else touches `color` in between, so the order of additions is the shader's), and
 // a last stage b == bounces only resolves.  Queue columns are reused: nee = Le*BRDF (3), cos_x, d^2, y (3);
 // bs = throughput before this bounce (3), pdf_light_area.  meta bit0: shadow ray present, bit3: prev_bounce_specular.
-__global__ __launch_bounds__(PT_SHADE_BLOCK) void k_shade_alt(ShadeArgs a)
+// 6 blocks per CU = 6 waves/SIMD: 80 VGPRs + 36 B of scratch.  Left alone the compiler takes 103 VGPRs (4 waves/SIMD); measured on
+// the bench scene, 32 frames, k_shade_alt ms (NEE / BRDF estimator): 4 waves 12.64 / 6.80, 5 waves 11.99 / 6.51, 6 waves 12.13 / 6.38.
+#ifndef PT_SHADE_ALT_MIN_BLOCKS
+#define PT_SHADE_ALT_MIN_BLOCKS 6
+#endif
+__global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_ALT_MIN_BLOCKS) void k_shade_alt(ShadeArgs a)
 {
 	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t in_region = blockIdx.x / a.blocks_per_region;

@@ -71,6 +71,20 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 
 #define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
 
+// Debug build only (-DPT_DEBUG_ITER_CAP, `make debug`: pathtracer_amd/libpt355_dbg.so).  k_trace ends because pt_upload_scene
+// proved the tree to be a tree and because the loop below steps every active lane in every iteration -- nothing in the kernel
+// itself bounds it, and a commit that moved the step calls behind an #else once produced a build that never returned
+// (b882dcd).  With this macro every lane counts the iterations of its ray; a ray past PT_DEBUG_ITER_CAP x (records of the
+// traversal blob) + 64 -- a tree walk visits every record at most once -- is abandoned, the count goes to DevCtl::iter_cap_hits,
+// and launch_trace (which then waits for every launch) returns PT_EHIP with a message: a failing test instead of a hung GPU.
+// -DPT_DEBUG_INJECT_STALL=n reproduces the fault for the test of the cap itself: a lane's first n iterations skip the step calls.
+#ifdef PT_DEBUG_ITER_CAP
+#if PT_DEBUG_ITER_CAP + 0 == 0
+#undef PT_DEBUG_ITER_CAP
+#define PT_DEBUG_ITER_CAP 4
+#endif
+#endif
+
 // tile-major path -> pixel map shared with pt_partition_pixels(): path p of this rank is pixel
 // (p % 64) of its (p / 64)-th own 8x8 tile; with PT_PARTITION_TILES tile t belongs to rank t % world.
 PT_DEV uint32_t path_pixel(uint32_t p, uint32_t width, uint32_t partition, uint32_t rank, uint32_t world)
@@ -141,7 +155,9 @@ struct DevScene {
 
 // device control block shared by the kernels of one context
 struct DevCtl {
-	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, wave_iters, top_steps, pad[9];
+	unsigned long long rays_primary, node_steps, tri_tests, stack_spills, paths, wave_iters, top_steps;
+	unsigned long long iter_cap_hits; // PT_DEBUG_ITER_CAP builds: rays abandoned because their traversal did not end
+	unsigned long long pad[8];
 	uint32_t qcount[2][PT_SHARDS * PT_SHARD_STRIDE];             // live entries of region r of queue q at [q][r*32]
 	uint32_t shard[PT_SHARDS * PT_SHARD_STRIDE];                 // trace work-unit counters, zeroed before each trace launch
 	unsigned long long rays_bounce[PT_SHARDS * (PT_SHARD_STRIDE / 2)]; // per-region statistics, summed by the host
@@ -306,6 +322,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	uint32_t sph_tk = 0, sph_prim = 0; // closest analytic sphere, found at refill (see below)
 	float t_kill = -__builtin_inff();  // shadow rays: an accepted hit with t <= t_kill ends the traversal
 	uint32_t n_steps = 0, n_tests = 0, n_spills = 0, n_iters = 0, n_top = 0; // n_iters: iterations of the traversal loop (wave-uniform)
+#ifdef PT_DEBUG_ITER_CAP
+	uint32_t dbg_iters = 0; // iterations of this lane's current ray
+	const uint32_t dbg_cap = (uint32_t) PT_DEBUG_ITER_CAP * (a.sc.tblob_bytes >> 6) + 64u;
+#endif
 	// wave-uniform work state
 	bool exhausted = false;
 	uint32_t loc_next = 0, loc_end = 0, loc_seg = 0; // the unit this wave is handing out to its lanes
@@ -545,6 +565,9 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						inv = V(rcp_of_q16(rd.x), rcp_of_q16(rd.y), rcp_of_q16(rd.z)); // fc:347: 1.0 / rd, bit for bit
 						tmax = PT_TMAX;
 						sp = 1; tri = 0; tri_end = 0;
+#ifdef PT_DEBUG_ITER_CAP
+						dbg_iters = 0;
+#endif
 						best_prim = 0xffffffffu; best_tk = 0; best_u = 0.0f; best_v = 0.0f;
 						// a root that is a leaf has no children to start from: spheres only
 						if (occluded_now) {
@@ -605,6 +628,16 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 				// all four loads are consumed here, in front of the mode branch: one memory round trip per iteration
 				// (left alone, the compiler sinks the fourth load into the node branch behind the first wait)
 				asm volatile("" : "+v"(q0.x), "+v"(q1.w), "+v"(q2.x), "+v"(q3.x), "+v"(q3.w));
+#ifdef PT_DEBUG_ITER_CAP
+				if (++dbg_iters > dbg_cap) { // this ray's traversal does not end: give it up and say so (see the top of this file)
+					atomicAdd(&a.ctl->iter_cap_hits, 1ull);
+					tri = 0; tri_end = 0; cur = PT_CUR_DONE;
+					break;
+				}
+#ifdef PT_DEBUG_INJECT_STALL
+				if (dbg_iters <= (uint32_t) PT_DEBUG_INJECT_STALL) continue; // the fault of b882dcd, bounded: no step calls
+#endif
+#endif
 				if (tmode) tri_step(q0, q1, q2);
 				else node_step(q0, q1, q2, q3);
 				// a retiring lane leaves the loop (its exec bit drops until the others follow); the rest go round again unless

@@ -52,7 +52,8 @@ struct Pipe {
 // (padded to 256-byte granules) + 2,048 waves (PT_NOALLOC_MAX_BLOCKS blocks) x 52 spill levels x 64 lanes x 4 B = 26 MiB.  Every GPU the
 // library is loaded on holds its own copy at its own address until the process ends; the array's NAME is a host-side
 // stand-in only and is never handed to a kernel or a hip* call: the per-device address from hipGetSymbolAddress is.
-#define PT_NOALLOC_MAX_BLOCKS (2048u / PT_TRACE_WAVES) /* 2048 waves: the whole chip at 8 waves per SIMD */
+#define PT_NOALLOC_MAX_BLOCKS (2048u / PT_TRACE_WAVES) /* 2048 waves = 2 waves per SIMD on 256 CUs: a QUARTER of pt_create's own grid (n_cu * 2 blocks of
+                                                          16 waves = 8 waves per SIMD); a spill tail for the full grid would be 104 MiB of static device memory per GPU */
 struct NoAllocScratch {
 	DevCtl ctl;
 	unsigned char pad[(256u - sizeof(DevCtl) % 256u) % 256u];
@@ -261,6 +262,26 @@ trace_kernel_t trace_kernel(bool count, bool gen, bool ieee_rcp)
 	return table[(count ? 1 : 0) | (gen ? 2 : 0) | (ieee_rcp ? 4 : 0)];
 }
 
+// PT_DEBUG_ITER_CAP builds (kernels_trace.h): wait for the trace launch just enqueued on `stream` and turn abandoned rays
+// into an error.  The debug library trades the asynchrony of every trace launch for that; the product build compiles to nothing.
+int check_iter_cap(pt_ctx *c, hipStream_t stream, DevCtl *ctl)
+{
+#ifdef PT_DEBUG_ITER_CAP
+	unsigned long long hits = 0;
+	HIP_TRY(c, hipMemcpyAsync(&hits, &ctl->iter_cap_hits, sizeof hits, hipMemcpyDeviceToHost, stream));
+	HIP_TRY(c, hipStreamSynchronize(stream));
+	if (hits) {
+		HIP_TRY(c, hipMemsetAsync(&ctl->iter_cap_hits, 0, sizeof hits, stream));
+		return fail(c, PT_EHIP, "k_trace: %llu ray(s) exceeded the traversal iteration cap (%u x %u records + 64) and were abandoned: "
+		            "the traversal loop does not terminate for them (malformed tree, or a loop that no longer steps)",
+		            hits, (unsigned) PT_DEBUG_ITER_CAP, (unsigned) (c->sc.tblob_bytes >> 6));
+	}
+#else
+	(void) c; (void) stream; (void) ctl;
+#endif
+	return PT_OK;
+}
+
 int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = false)
 {
 	const bool timed = begin_timed(c, pp, 0);
@@ -270,7 +291,7 @@ int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = fa
 	end_timed(c, pp, timed);
 	c->trace_launches++;
 	HIP_TRY(c, hipGetLastError());
-	return PT_OK;
+	return check_iter_cap(c, pp.stream, ta.ctl);
 }
 
 TraceArgs queue_trace_args(pt_ctx *c, Pipe &pp, uint32_t qi, bool with_shadow)
@@ -371,8 +392,9 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	// 32 -> 8.59 (r01g kernel).
 	c->max_batch = cfg->max_batch ? cfg->max_batch : (uint32_t) PT_MAX_BATCH;
 	if (c->max_batch > PT_MAX_BATCH) c->max_batch = PT_MAX_BATCH;
-	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 26)) c->max_batch--;
 	if (const char *e = getenv("PT355_BATCH")) { int v = atoi(e); if (v >= 1 && v <= PT_MAX_BATCH) c->max_batch = (uint32_t) v; }
+	// applied to the override too: k_shade keeps a path's id as (id << 4) | flags in one word, so ids must stay below 2^28
+	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 26)) c->max_batch--;
 	// queue geometry: PT_SHARDS regions of `cap` slots, cap a whole number of shading blocks (kernels_trace.h)
 	{
 		const uint32_t n_blocks = (uint32_t) (((uint64_t) c->max_batch * c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK);
@@ -445,8 +467,10 @@ int pt_destroy(pt_ctx *c)
 // (so the walk from the root is a tree walk and ends).
 static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<uint32_t> &blob, uint32_t *n_records, bool *short_rcp)
 {
-	// |det| = |e1 . (rd x e2)| <= 2 |rd|_inf |e1|_1 |e2|_1 with |rd|_inf <= 1 (a normalised direction rounded to fp16); the
-	// factor 16 leaves room for the roundings.  Stays below 2^126 for anything but absurd coordinates.
+	// |det| = |e1 . (rd x e2)| <= 2 |rd|_inf |e1|_1 |e2|_1.  The traversal ray is q16(rd) (fc:437), so |rd|_inf <= 65504 whatever
+	// the caller hands over: the renderer's directions are normalised, but pt_trace_closest* trace the caller's own rays and
+	// nothing normalises those.  The bound takes the fp16 maximum (2^16 for short) and a factor 16 for the roundings: 2^21 |e1|_1
+	// |e2|_1.  Still below 2^126 for anything but absurd coordinates (edges of ~2^52).
 	double det_bound = 0.0;
 	const float *nd = (const float *) s->nodes;
 	const float *tr = (const float *) s->tris;
@@ -529,7 +553,7 @@ static int build_traversal_blob(pt_ctx *c, const pt_scene_desc *s, std::vector<u
 				{
 					double l1[2] = {0.0, 0.0};
 					for (int a = 0; a < 3; a++) { l1[0] += fabs((double) (src[4 + a] - v0[a])); l1[1] += fabs((double) (src[8 + a] - v0[a])); }
-					const double b = 16.0 * l1[0] * l1[1];
+					const double b = 16.0 * 2.0 * 65536.0 * l1[0] * l1[1];
 					if (!(b <= det_bound)) det_bound = b; // NaN / inf make the bound NaN / inf: the short form is then off
 				}
 				d[3] = (uint32_t) t;
@@ -885,7 +909,9 @@ int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n,
 	if (!c->noalloc) return fail(c, PT_ESTATE, "pt_trace_closest_device_noalloc: no static scratch on device %d (ordinal above %d)", c->cfg.device, PT_MAX_DEVICES - 1);
 	if (n == 0) return PT_OK;
 	HIP_TRY(c, hipSetDevice(c->cfg.device));
-	if (c->in_flight) { int rc = join(c); if (rc) return rc; }
+	// no implicit join here: a stream synchronisation is not something a caller under graph capture can take, and renders in
+	// flight own the streams this call would have to wait for.  pt_sync first.
+	if (c->in_flight) return fail(c, PT_ESTATE, "pt_trace_closest_device_noalloc: renders are in flight on this context: call pt_sync first (this entry point never synchronises)");
 	NoAllocScratch *const sp = c->noalloc; // the device address, never the array's name
 	HIP_TRY(c, hipMemsetAsync(&sp->ctl, 0, sizeof(DevCtl), c->stream));
 	TraceArgs ta;
@@ -901,7 +927,7 @@ int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n,
 	const uint32_t grid = (uint32_t) c->trace_grid < PT_NOALLOC_MAX_BLOCKS ? (uint32_t) c->trace_grid : PT_NOALLOC_MAX_BLOCKS;
 	hipLaunchKernelGGL(trace_kernel(false, false, ta.sc.short_rcp == 0u), dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
 	HIP_TRY(c, hipGetLastError());
-	return PT_OK;
+	return check_iter_cap(c, c->stream, ta.ctl); // debug builds only; allocates nothing either way
 }
 
 int pt_trace_closest(pt_ctx *c, const float *ro, const float *rd, uint32_t n, uint32_t *prim, uint16_t *t_h, uint8_t *kind, float *uv)

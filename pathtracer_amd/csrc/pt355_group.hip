@@ -135,12 +135,27 @@ int pt_group_create(const pt_config *cfg, const int32_t *devices, uint32_t n_dev
 		CREATE_TRY(hipSetDevice(devices[i]));
 		CREATE_TRY(hipStreamCreate(&g->copy_stream[i]));
 		if (devices[i] != devices[0]) {
-			// peer access is an optimisation (direct xGMI instead of a bounce through host memory): failure is not an error
-			int can = 0;
-			if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) (void) hipDeviceEnablePeerAccess(devices[0], 0);
-			(void) hipGetLastError();
-			if (hipSetDevice(devices[0]) == hipSuccess && hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can) (void) hipDeviceEnablePeerAccess(devices[i], 0);
-			(void) hipGetLastError(); // "already enabled" included
+			// peer access is an optimisation (direct xGMI instead of a bounce through host memory): without it hipMemcpyPeerAsync
+			// stages the copy itself, so a failure does not fail the group -- but it is REPORTED: pt_group_last_error of a
+			// successfully created group says which pair runs on staged copies and why
+			auto enable = [&](int from, int to) {
+				int can = 0;
+				hipError_t e = hipSetDevice(from);
+				if (e == hipSuccess) e = hipDeviceCanAccessPeer(&can, from, to);
+				if (e == hipSuccess && can) {
+					e = hipDeviceEnablePeerAccess(to, 0);
+					if (e == hipErrorPeerAccessAlreadyEnabled) e = hipSuccess;
+				}
+				(void) hipGetLastError();
+				if (e != hipSuccess || !can) {
+					char buf[256];
+					snprintf(buf, sizeof buf, "%spt_group_create: no peer access from device %d to device %d (%s): gathers between them use staged copies",
+					         g->err.empty() ? "" : "; ", from, to, e != hipSuccess ? hipGetErrorString(e) : "hipDeviceCanAccessPeer says no");
+					g->err += buf;
+				}
+			};
+			enable(devices[i], devices[0]);
+			enable(devices[0], devices[i]);
 			CREATE_TRY(hipSetDevice(devices[i]));
 		}
 		if (i > 0 && mode == PT_GROUP_TILES) CREATE_TRY(hipMalloc(&g->staging_src[i], bytes ? bytes : 16));

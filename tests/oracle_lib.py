@@ -128,7 +128,7 @@ def render(osc, cam12, width, height, seeds, first_frame=0, bounces=5, flags=0, 
 
 # oracle_probe: name -> (code, floats in, floats out) per record (oracle/oracle.h)
 PROBE = dict(MAP_TO_UNIT_SPHERE=(0, 2, 3), TNB_ROWS=(1, 3, 9), MAP_TO_TRIANGLE=(2, 11, 3), COSINE_HEMISPHERE=(3, 5, 3), NDF=(4, 4, 1),
-             PICK_WI=(5, 6, 8), CALC_BRDF=(6, 18, 3), OCT_DECODE=(7, 1, 3), INVERSE3=(8, 9, 9))
+             PICK_WI=(5, 6, 8), CALC_BRDF=(6, 18, 3), OCT_DECODE=(7, 1, 3), INVERSE3=(8, 9, 9), PRIMARY_RAY=(9, 17, 7))
 
 
 def probe(what, records, flags=0):

@@ -34,7 +34,7 @@ def test_plain_shell_start_spawns_ranks_that_refuse_to_run_without_a_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("partition", ["tiles", "samples"])
 def test_two_ranks_from_a_plain_shell(partition):
-    r = _run(["--partition", partition, "--check", "--scene", "cornell"], 300)
+    r = _run(["--partition", partition, "--scene", "cornell", "--sustain", "0.2"], 300)  # the N > 1 self-check runs by default
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(line) == 1                               # rank 0 prints ONE JSON line
@@ -43,4 +43,11 @@ def test_two_ranks_from_a_plain_shell(partition):
     assert d["config"]["partition"] == ("tiles" if partition == "tiles" else "samples-interleaved")
     assert d["scaling"] == ("strong" if partition == "tiles" else "weak")
     assert d["check"]["ok"] is True
+    # who took part: one entry per rank with its device, so that a scaling line says by itself whether
+    # N ranks sat on N distinct GPUs -- here both ranks share the box's one GPU, and the line says so
+    assert d["world_size"] == 2 and [r["rank"] for r in d["ranks_seen"]] == [0, 1]
+    for r in d["ranks_seen"]:
+        assert r["device"] and r["pci_bus_id"] and r["backend"] == "gloo"
+    assert d["distinct_devices"] == 1
+    assert d["sustained"]["regions"] >= 1 and d["sustained_ms_per_step"] > 0
     assert d["roofline"]["frac"] is None or d["roofline"]["frac"] <= 1.0

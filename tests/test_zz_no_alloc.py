@@ -52,3 +52,41 @@ def test_noalloc_entry_matches_the_allocating_one(pt, ol):
             c.trace_closest_device_noalloc(d_ray.data_ptr(), (1 << 26) + 1, got.data_ptr())
     finally:
         c.close()
+
+
+def test_noalloc_entry_never_synchronises_and_its_rate(pt):
+    """With renders of the context in flight the entry point returns PT_ESTATE instead of waiting for them (a caller under
+    graph capture cannot take a stream synchronisation); after pt_sync it runs.  Also prints its rate next to the
+    allocating entry's: the grid is capped at 2,048 waves, a quarter of pt_create's (INTEGRATION.md quotes the figure)."""
+    import time
+
+    import torch
+
+    scene = pt.Scene.bunny(spheres=True)
+    c = pt.PathTracer(64, 64)
+    try:
+        c.upload_scene(scene)
+        c.set_camera(pt.default_camera())
+        n = 4 << 20
+        d_ray = torch.from_numpy(_rays_soa(n, 5)).cuda()
+        a = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        b = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        c.render(0, pt.frame_seeds(0, 2), 5)
+        with pytest.raises(pt.PtError, match="pt_sync first"):
+            c.trace_closest_device_noalloc(d_ray.data_ptr(), n, b.data_ptr())
+        c.sync()
+        rates = {}
+        for name, fn, out in (("alloc", c.trace_closest_device, a), ("noalloc", c.trace_closest_device_noalloc, b)):
+            fn(d_ray.data_ptr(), n, out.data_ptr())
+            c.sync()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn(d_ray.data_ptr(), n, out.data_ptr())
+            c.sync()
+            rates[name] = 5 * n / (time.perf_counter() - t0) / 1e9
+        print(f"trace entries on {n} incoherent rays: pt_trace_closest_device {rates['alloc']:.2f} Grays/s, "
+              f"pt_trace_closest_device_noalloc {rates['noalloc']:.2f} Grays/s ({rates['noalloc'] / rates['alloc']:.2f} x)")
+        assert torch.equal(a, b)
+    finally:
+        c.close()

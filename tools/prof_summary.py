@@ -168,6 +168,10 @@ if tr:
 if False and "k_trace" in kern and plain.get("trace_launches"):
     kern["k_trace"]["rays_per_launch"] = plain["rays"] / plain["trace_launches"]
 if kern:
-    json.dump({"workload": "bunny-1920x1080-b5", "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.setdefault("PT355_NO_TORCH", "1")
+    import pathtracer_amd  # only for the stamp: the device sources these counters were taken on
+    json.dump({"workload": "bunny-1920x1080-b5", "kernel_sha256": pathtracer_amd.kernel_source_sha256(), "kernel_sources": list(pathtracer_amd.KERNEL_SOURCES),
+               "source": f"profiles/{tag}_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
                "over pathtracer_amd/ptbench; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
                "kernels": kern}, open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w"), indent=1)
