@@ -150,6 +150,10 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
+    if os.environ.get("PT355_BENCH_WATCHDOG"):
+        # a rank that hangs (a collective one side never enters) prints every thread's stack and exits instead of sitting silent
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PT355_BENCH_WATCHDOG"]), exit=True)
 
     import numpy as np
     import torch
@@ -174,6 +178,9 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     tiles = world > 1 and args.partition == "tiles"
+    # where the few-byte control reductions (times, counts) live: RCCL reduces device tensors; gloo is given host tensors -- its
+    # CUDA path deadlocked now and then with two ranks on one GPU (both ranks inside the same all_reduce, r03 watchdog dump)
+    ctl_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     K, W = args.steps, args.warmup
 
     t_scene = time.perf_counter()
@@ -216,7 +223,10 @@ def main():
         ctx.sync()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            if args.dist_backend == "nccl":
+                dist.barrier()
+            else:
+                dist.all_reduce(torch.zeros(1))  # a host-side barrier: gloo's barrier() picks the CUDA path when a device is current
             torch.cuda.synchronize()
 
     def exchange(n_local, n_total):
@@ -275,7 +285,7 @@ def main():
         dt = time.perf_counter() - t0
         cnt = ctx.counters()
         if dist is not None:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([dt], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         regions.append((dt, cnt))
@@ -297,7 +307,7 @@ def main():
                 exchange(K, K * (1 if tiles else world))
             n_reg += 1
             ctx.sync()
-            el = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device="cuda")
+            el = torch.tensor([time.perf_counter() - s0], dtype=torch.float64, device=ctl_dev)
             if dist is not None:
                 dist.all_reduce(el, op=dist.ReduceOp.MAX)  # every rank takes the same decision
             if float(el.item()) >= args.sustain or n_reg >= 100000:
@@ -305,13 +315,13 @@ def main():
         sync_all()
         sdt = time.perf_counter() - s0
         if dist is not None:
-            tmax = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([sdt], dtype=torch.float64, device=ctl_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             sdt = float(tmax.item())
         sustained = {"seconds": round(sdt, 3), "regions": n_reg, "steps": n_reg * K, "ms_per_step": round(sdt / (n_reg * K) * 1e3, 4)}
 
     if dist is not None:
-        tot = torch.tensor([rays, cnt["paths"]], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([rays, cnt["paths"]], dtype=torch.int64, device=ctl_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         rays_total, paths_total = int(tot[0].item()), int(tot[1].item())
     else:

@@ -69,7 +69,12 @@ typedef uint32_t pt_u32x4 __attribute__((ext_vector_type(4)));
 #define PT_SHARDS 64
 #define PT_SHARD_STRIDE 32   // u32 words between two counters = 128 bytes
 
+#ifndef PT_MAX_BATCH
 #define PT_MAX_BATCH 32   // frames (samples per pixel) traced together by one set of launches
+#endif
+#ifndef PT_MAX_PATHS_LOG2
+#define PT_MAX_PATHS_LOG2 26 // ... and at most this many paths (2^26 = ~23 GB of queues); k_shade packs (path id << 4) | flags into one word: < 2^28
+#endif
 
 // Debug build only (-DPT_DEBUG_ITER_CAP, `make debug`: pathtracer_amd/libpt355_dbg.so).  k_trace ends because pt_upload_scene
 // proved the tree to be a tree and because the loop below steps every active lane in every iteration -- nothing in the kernel

@@ -394,7 +394,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	if (c->max_batch > PT_MAX_BATCH) c->max_batch = PT_MAX_BATCH;
 	if (const char *e = getenv("PT355_BATCH")) { int v = atoi(e); if (v >= 1 && v <= PT_MAX_BATCH) c->max_batch = (uint32_t) v; }
 	// applied to the override too: k_shade keeps a path's id as (id << 4) | flags in one word, so ids must stay below 2^28
-	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << 26)) c->max_batch--;
+	while (c->max_batch > 1 && (uint64_t) c->max_batch * c->n_paths > (1ull << PT_MAX_PATHS_LOG2)) c->max_batch--;
 	// queue geometry: PT_SHARDS regions of `cap` slots, cap a whole number of shading blocks (kernels_trace.h)
 	{
 		const uint32_t n_blocks = (uint32_t) (((uint64_t) c->max_batch * c->n_paths + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK);

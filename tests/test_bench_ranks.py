@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(extra, timeout):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PT355_BENCH_WATCHDOG"] = "100"  # a hung rank dumps its stacks and exits: a failure with a traceback, not a silent timeout
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "4", "--warmup", "1",
            "--width", "256", "--height", "128", "--no-cpu-baseline"] + extra
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
