@@ -378,7 +378,7 @@ int pt_create(const pt_config *cfg, pt_ctx **out)
 	CREATE_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, k_trace<false, false, false>, PT_TRACE_BLOCK, 0));
 	if (blocks_per_cu < 1) blocks_per_cu = 1;
 	if (blocks_per_cu > 8) blocks_per_cu = 8;
-	// tuning knobs for experiments (tools/exp_*.py), read once per pt_create; defaults are the measured optimum (DESIGN.md
+	// tuning knobs for experiments (tools/experiments/exp_*.py), read once per pt_create; defaults are the measured optimum (DESIGN.md
 	// section 7): PT355_PIPES (1..4), PT355_TRACE_BLOCKS_PER_CU, PT355_REFILL (1..64), PT355_BATCH (1..32), PT355_FUSED_PRIMARY (0/1).  None changes results.
 	if (const char *e = getenv("PT355_TRACE_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= blocks_per_cu) blocks_per_cu = v; }
 	if (const char *e = getenv("PT355_FUSED_PRIMARY")) c->fused_primary = atoi(e) != 0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the two dormant estimators (k_shade_alt) on the bench workload: exp_alt.py [frames]   (PT355_LIB selects the build)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import pathtracer_amd as pt
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32

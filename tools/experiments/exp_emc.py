@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU builders with plain vs extended Morton codes (PT355_BVH_PLAIN_MORTON set / unset) on the bench mesh and on the atrium (GPU box)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 def run(scene, label, tex=None):

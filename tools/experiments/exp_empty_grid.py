@@ -3,7 +3,7 @@
 misses, the stages after stage 0 find nothing in their queues, yet their grids cover every slot."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 base = pt.Scene.soup(2, seed=3).arrays()

@@ -2,7 +2,7 @@
 """Does a traversal blob that fits the XCD's 4 MiB L2 trace faster per step? (GPU box)  The bench mesh at 9 k … 70 k
 triangles (0.9 … 7 MB of blob), 1080p MIS, Sweep-SAH tree: trace time per (node-pair step + triangle test)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 for freq in [int(x) for x in sys.argv[1:]] or (21, 30, 36, 42, 48, 53, 59, 70, 84):

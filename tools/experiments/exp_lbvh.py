@@ -2,7 +2,7 @@
 """Bench scene traced through the reference builder's Sweep-SAH tree vs the GPU-built LBVH (GPU box only)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 def run(scene, label, flags=0):

@@ -2,7 +2,7 @@
 """PLOC trees of the bench mesh (69 k and 1 M triangles): build time, S, T and Grays/s (GPU box).  Run with a library built with
 another -DPLOC_RADIUS to compare search radii (tools/exp_build.sh + LD path is not needed: the package loads pathtracer_amd/libpt355.so)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 def run(scene, label):

@@ -3,7 +3,7 @@
 tree from the CPU builder, LBVH and PLOC trees from the GPU builders."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import pathtracer_amd as pt
 
 def run(scene, label):
