@@ -302,6 +302,7 @@ def main():
         s0 = time.perf_counter()
         n_reg = 0
         while True:
+            ctx.clear_framebuffer()  # as in the timed regions (frame 0 overwrites the image anyway, except where it holds NaN)
             ctx.render(0, timed, args.bounces)
             if dist is not None:
                 exchange(K, K * (1 if tiles else world))
