@@ -40,6 +40,7 @@ struct ShadeArgs {
 	uint32_t stride;
 	uint32_t cap;           // slots per queue region = blocks_per_region * PT_SHADE_BLOCK
 	uint32_t blocks_per_region;
+	uint32_t launch_bpr;    // blocks launched per region by the queue-driven stages (<= blocks_per_region)
 	DevCtl *ctl;
 	uint32_t in_q;          // index of `in` in ctl->qcount
 	float cam[12];
@@ -501,8 +502,11 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK) void k_resolve(ShadeArgs a)
 template <bool PRIMARY>
 __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(ShadeArgs a)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t in_region = PRIMARY ? 0u : blockIdx.x / a.blocks_per_region; // cap is a multiple of the block size
+	// launch_bpr blocks are launched per region: the front of each region up to the largest fill this batch can produce
+	// (region_block_bound in pt355.hip), not every slot of a queue sized for the largest batch
+	const uint32_t in_region = PRIMARY ? 0u : blockIdx.x / a.launch_bpr;
+	const uint32_t block_off = (blockIdx.x - in_region * a.launch_bpr) * PT_SHADE_BLOCK; // first slot of this block inside its region
+	const uint32_t i = PRIMARY ? blockIdx.x * blockDim.x + threadIdx.x : in_region * a.cap + block_off + threadIdx.x;
 	const uint32_t n_in = PRIMARY ? a.n_batch * a.n_paths_frame : a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
 	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
 	if (PRIMARY && i == 0) { // what k_raygen counts
@@ -511,10 +515,10 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 	}
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
-	// a block wholly past its region's fill has nothing to read and nothing to claim (the grid covers every slot of
-	// the queue because the fill counts live on the device): leave before the block-wide compaction
-	if (blockIdx.x * blockDim.x - in_region * a.cap >= n_in) return;
-	bool alive = i - in_region * a.cap < n_in;
+	// a block wholly past its region's fill has nothing to read and nothing to claim (the fill counts live on the device, so
+	// the grid covers the bound, not the fill): leave before the block-wide compaction
+	if (block_off >= n_in) return;
+	bool alive = block_off + threadIdx.x < n_in;
 
 	uint32_t pixel = 0 /* path id in the batch */, rng = 0, meta = 0;
 	v3 thr = V(0, 0, 0), col = V(0, 0, 0), ro = V(0, 0, 0), rd = V(0, 0, 0);
@@ -695,17 +699,16 @@ __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_MIN_BLOCKS) void k_shade(S
 #endif
 __global__ __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_ALT_MIN_BLOCKS) void k_shade_alt(ShadeArgs a)
 {
-	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t in_region = blockIdx.x / a.blocks_per_region;
+	const uint32_t in_region = blockIdx.x / a.launch_bpr; // as in k_shade
+	const uint32_t block_off = (blockIdx.x - in_region * a.launch_bpr) * PT_SHADE_BLOCK;
+	const uint32_t i = in_region * a.cap + block_off + threadIdx.x;
 	const uint32_t n_in = a.ctl->qcount[a.in_q][in_region * PT_SHARD_STRIDE];
 	if (i < PT_SHARDS) a.ctl->shard[i * PT_SHARD_STRIDE] = 0; // for the trace launch that follows
 	const uint32_t st = a.stride;
 	const DevScene &sc = a.sc;
 	const bool nee_est = a.estimator == PT_EST_NEE;
-	// a block wholly past its region's fill has nothing to read and nothing to claim (the grid covers every slot of
-	// the queue because the fill counts live on the device): leave before the block-wide compaction
-	if (blockIdx.x * blockDim.x - in_region * a.cap >= n_in) return;
-	bool alive = i - in_region * a.cap < n_in;
+	if (block_off >= n_in) return; // wholly past the region's fill: leave before the block-wide compaction
+	bool alive = block_off + threadIdx.x < n_in;
 	bool emit_bounce = false, emit_shadow = false;
 
 	uint32_t pid = 0, rng = 0, meta = 0, new_meta = 0;

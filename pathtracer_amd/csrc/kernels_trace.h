@@ -192,6 +192,8 @@ struct TraceArgs {
 	uint32_t n_segs;
 	uint32_t refill_threshold; // refill when at least this many lanes of the wave are idle
 	uint32_t shadow_mode;      // PT_SHADOW_* for rays that carry a target
+	uint32_t peek;             // small launches: look at a region's unit counter before spending an atomic on it (see the unit fetch)
+	uint32_t unit_shift;       // a wave claims 1 << unit_shift rays (64 .. 512) with one atomic on its region's work counter
 	DevCtl *ctl;
 	uint32_t *zero_on_entry;   // optional: region counters of the queue the next shading kernel fills, cleared by block 0
 	uint32_t *spill;           // [gridDim.x * PT_TRACE_WAVES][PT_SPILL_STACK][64]
@@ -337,6 +339,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	uint32_t shard = (blockIdx.x * PT_TRACE_WAVES + wave) % PT_SHARDS, shards_done = 0;
 	uint32_t shard_count = 0, shard_units = 0;
 	bool shard_known = false;
+	// rays per work unit.  The returning atomic that claims a unit is a round trip of 2-3 us which the wave sits out: at 64 rays a
+	// unit that was 6 % of a batch launch; 256 is the optimum there (512: the last units unbalance the drain), 64 for a launch of
+	// one small frame, where larger units would leave waves without work.  The host chooses (trace_launch_shape in pt355.hip).
+	const uint32_t unit_rays = 1u << a.unit_shift;
 
 	// a lane is busy while it has a record to visit or triangles pending; finished, refused and never-filled lanes all look alike
 	auto is_active = [&]() { return tri < tri_end || cur != PT_CUR_DONE; };
@@ -480,10 +486,17 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 						if (a.count_ptr) cnt = a.count_ptr[shard * PT_SHARD_STRIDE];
 						else { const uint32_t lo = shard * a.cap; cnt = a.n_fixed > lo ? (a.n_fixed - lo < a.cap ? a.n_fixed - lo : a.cap) : 0u; }
 						shard_count = (uint32_t) __builtin_amdgcn_readfirstlane((int) (cnt < a.cap ? cnt : a.cap));
-						shard_units = (shard_count + 63u) >> 6;
+						shard_units = (shard_count + unit_rays - 1u) >> a.unit_shift;
 						shard_known = true;
 					}
-					if (shard_units) {
+					// A launch of a frame or two is over before most waves have seen their second unit: towards its end every wave walks
+					// the dry regions one returning atomic (a round trip to L2) at a time.  With a.peek a plain load of the counter
+					// comes first and a region seen dry costs no atomic: the one-frame launch -16 %.  Off for batches, where the
+					// extra round trip in front of EVERY unit costs more than the dry tail saves (EXPERIMENTS.md section 6).
+					bool open = shard_units != 0u;
+					if (open && a.peek)
+						open = __hip_atomic_load(&a.ctl->shard[shard * PT_SHARD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < shard_units * a.n_segs;
+					if (open) {
 						uint32_t u = 0;
 						if (lane == 0) u = atomicAdd(&a.ctl->shard[shard * PT_SHARD_STRIDE], 1u);
 						u = (uint32_t) __builtin_amdgcn_readfirstlane((int) u);
@@ -491,8 +504,8 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 							loc_seg = u >= shard_units ? 1u : 0u;
 							const uint32_t idx = u - loc_seg * shard_units;
 							const uint32_t base = shard * a.cap;
-							loc_next = base + (idx << 6);
-							loc_end = loc_next + 64u < base + shard_count ? loc_next + 64u : base + shard_count;
+							loc_next = base + (idx << a.unit_shift);
+							loc_end = loc_next + unit_rays < base + shard_count ? loc_next + unit_rays : base + shard_count;
 							found = true;
 							break;
 						}

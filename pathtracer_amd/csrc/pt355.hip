@@ -282,6 +282,17 @@ int check_iter_cap(pt_ctx *c, hipStream_t stream, DevCtl *ctl)
 	return PT_OK;
 }
 
+// How a trace launch hands out its rays, from an upper bound of their number (the fill counts themselves live on the device).
+// Work-unit size and the dry-region peek only move work between waves: results do not depend on them.
+void trace_launch_shape(TraceArgs &ta, uint32_t rays_bound /* paths of the batch, or rays of a trace call */)
+{
+	// measured on the bench scene, launch sets of 1..32 frames at 720p and 1080p (tools/experiments/exp_small_launch_sweep.sh)
+	ta.unit_shift = rays_bound <= (1u << 20) ? 6u : rays_bound <= 3u * (1u << 23) ? 7u : 8u;
+	ta.peek = rays_bound <= (1u << 22) ? 1u : 0u;
+	if (const char *e = getenv("PT355_EXP_UNIT")) { int v = atoi(e); if (v >= 6 && v <= 9) ta.unit_shift = (uint32_t) v; }
+	if (const char *e = getenv("PT355_EXP_PEEK")) ta.peek = atoi(e) != 0;
+}
+
 int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = false)
 {
 	const bool timed = begin_timed(c, pp, 0);
@@ -294,7 +305,7 @@ int launch_trace(pt_ctx *c, Pipe &pp, const TraceArgs &ta, bool gen_primary = fa
 	return check_iter_cap(c, pp.stream, ta.ctl);
 }
 
-TraceArgs queue_trace_args(pt_ctx *c, Pipe &pp, uint32_t qi, bool with_shadow)
+TraceArgs queue_trace_args(pt_ctx *c, Pipe &pp, uint32_t qi, bool with_shadow, uint32_t n_paths_bound)
 {
 	TraceArgs ta;
 	memset(&ta, 0, sizeof ta);
@@ -312,6 +323,7 @@ TraceArgs queue_trace_args(pt_ctx *c, Pipe &pp, uint32_t qi, bool with_shadow)
 	ta.ctl = pp.ctl;
 	ta.zero_on_entry = pp.ctl->qcount[qi ^ 1u];
 	ta.spill = pp.spill;
+	trace_launch_shape(ta, n_paths_bound);
 	return ta;
 }
 
@@ -722,7 +734,15 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	const dim3 sblock(PT_SHADE_BLOCK);
 	// shading blocks that cover the occupied prefix of every region would need a 2-D launch; regions past the batch's
 	// own size are empty and their blocks return after one load, so the grid simply covers every slot
-	const dim3 sgrid(c->stride / PT_SHADE_BLOCK);
+	// A region's fill never exceeds the slots of the blocks that append to it.  k_raygen fills region r with <= per_region paths;
+	// the fused primary stage runs ceil(n_total / block) blocks of which every 64th appends to region r; a queue-driven stage
+	// of 64 * L blocks gives every region exactly L appenders.  So L blocks per region cover every fill of this batch:
+	const uint32_t primary_blocks = (n_total + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
+	uint32_t L = (sa.per_region + PT_SHADE_BLOCK - 1) / PT_SHADE_BLOCK;
+	if ((primary_blocks + PT_SHARDS - 1) / PT_SHARDS > L) L = (primary_blocks + PT_SHARDS - 1) / PT_SHARDS;
+	if (L > c->blocks_per_region) L = c->blocks_per_region; // = cap / block: the bound of the largest batch
+	sa.launch_bpr = L;
+	const dim3 sgrid(PT_SHARDS * L);
 
 	sa.out = pp.q[0];
 	// Fused primary stage (MIS): no k_raygen launch.  k_trace generates the camera ray of path p at refill and k_shade
@@ -737,7 +757,7 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 	uint32_t qi = 0;
 	if (c->estimator == PT_EST_MIS) {
 		for (uint32_t stage = 0; stage <= sa.bounces; stage++) {
-			TraceArgs ta = queue_trace_args(c, pp, qi, stage > 0);
+			TraceArgs ta = queue_trace_args(c, pp, qi, stage > 0, n_total);
 			const bool primary = fused && stage == 0;
 			if (primary) {
 				ta.seg[0].ray = nullptr;
@@ -763,7 +783,7 @@ static int render_batch(pt_ctx *c, uint32_t first_frame, uint32_t n_batch, const
 		const bool nee = c->estimator == PT_EST_NEE;
 		const uint32_t n_stages = sa.bounces ? sa.bounces + (nee ? 1u : 0u) : 0u;
 		for (uint32_t stage = 0; stage < n_stages; stage++) {
-			TraceArgs ta = queue_trace_args(c, pp, qi, nee && stage > 0);
+			TraceArgs ta = queue_trace_args(c, pp, qi, nee && stage > 0, n_total);
 			ta.shadow_mode = PT_SHADOW_FULL; // this estimator's compare is two-sided (fc:821): no early-out rule built for it
 			if (nee && stage == sa.bounces) { ta.seg[0] = ta.seg[1]; ta.n_segs = 1; } // only shadow rays are left
 			int rc = launch_trace(c, pp, ta);
@@ -891,6 +911,7 @@ int pt_trace_closest_device(pt_ctx *c, const void *ray6_dev, uint32_t n, void *h
 	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = pp.ctl;
 	ta.spill = pp.spill;
+	trace_launch_shape(ta, n);
 	return launch_trace(c, pp, ta);
 }
 
@@ -923,6 +944,7 @@ int pt_trace_closest_device_noalloc(pt_ctx *c, const void *ray6_dev, uint32_t n,
 	ta.refill_threshold = c->refill_threshold;
 	ta.ctl = &sp->ctl;
 	ta.spill = sp->spill;
+	trace_launch_shape(ta, n);
 	// the spill tail is sized for PT_NOALLOC_MAX_BLOCKS blocks: k_trace is persistent, any grid drains the work counters
 	const uint32_t grid = (uint32_t) c->trace_grid < PT_NOALLOC_MAX_BLOCKS ? (uint32_t) c->trace_grid : PT_NOALLOC_MAX_BLOCKS;
 	hipLaunchKernelGGL(trace_kernel(false, false, ta.sc.short_rcp == 0u), dim3(grid), dim3(PT_TRACE_BLOCK), 0, c->stream, ta);
