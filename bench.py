@@ -439,7 +439,9 @@ def main():
     # cache-served, so this "fraction" exceeds 1 and is NOT the binding roof; hbm_counter_frac is the HBM-side truth.
     bytes_per_ray = 64.0 * S + 64.0 * T + 96.0
     alg = bytes_per_ray * rays_per_launch / sec / 1e9 if sec > 0 else 0.0
-    lead = valu if (valu and (vmem["frac"] is None or valu["frac"] >= vmem["frac"])) else vmem
+    # the two fractions sit within a point or two of each other (0.64 / 0.65): inside a band of 0.02 the line leads with VALU issue, the
+    # resource the experiments single out (EXPERIMENTS.md section 1), so that the headline does not flip between runs
+    lead = valu if (valu and (vmem["frac"] is None or valu["frac"] >= vmem["frac"] - 0.02)) else vmem
     other = vmem if lead is valu else valu
     roofline = {"kernel": "k_trace"}
     roofline.update(lead)
