@@ -339,9 +339,10 @@ __global__ __launch_bounds__(PT_TRACE_BLOCK, PT_TRACE_MIN_WAVES) void k_trace(Tr
 	uint32_t shard = (blockIdx.x * PT_TRACE_WAVES + wave) % PT_SHARDS, shards_done = 0;
 	uint32_t shard_count = 0, shard_units = 0;
 	bool shard_known = false;
-	// rays per work unit.  The returning atomic that claims a unit is a round trip of 2-3 us which the wave sits out: at 64 rays a
-	// unit that was 6 % of a batch launch; 256 is the optimum there (512: the last units unbalance the drain), 64 for a launch of
-	// one small frame, where larger units would leave waves without work.  The host chooses (trace_launch_shape in pt355.hip).
+	// rays per work unit.  The returning atomic that claims a unit is a round trip of 2-3 us which the wave sits out, and a refill that
+	// finds its unit short stays partial (lanes idle until the next one): at 64 rays a unit the two cost 6 % of a batch launch.  256 is
+	// the measured optimum there (512 is slower again, with or without small units at a region's end: EXPERIMENTS.md section 6), 64 for
+	// a launch of one small frame, where larger units would leave waves without work.  The host chooses (trace_launch_shape, pt355.hip).
 	const uint32_t unit_rays = 1u << a.unit_shift;
 
 	// a lane is busy while it has a record to visit or triangles pending; finished, refused and never-filled lanes all look alike
